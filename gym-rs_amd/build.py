@@ -1,0 +1,93 @@
+"""Builds the native parts in-tree.
+
+  gym-rs_amd/libgymrs_amd.so        HIP kernels + C ABI, hipcc --offload-arch=gfx950 (the PRODUCT)
+  oracle/build/libgymrs_oracle.so   f64 C restatement of the reference (TEST infrastructure)
+  oracle/build/libgymrs_f32twin.so  host build of the product's shared physics header (TEST infra)
+
+Run as `python gym-rs_amd/build.py [--force]`, or through `__graft_entry__.build()`.
+hipcc cross-compiles for gfx950 without a GPU.  The built .so files are git-ignored but travel to
+the GPU box with gpurun.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+ROOT = PKG.parent
+CSRC = PKG / "csrc"
+ORACLE = ROOT / "oracle"
+
+HIP_SOURCES = [CSRC / "gymrs_kernels.hip", CSRC / "gymrs_engine.hip"]
+HIP_HEADERS = [
+    CSRC / "gymrs_kernels.h",
+    CSRC / "gymrs_physics.h",
+    CSRC / "gymrs_philox.h",
+    CSRC / "gymrs_math.h",
+    ROOT / "include" / "gymrs_amd.h",
+]
+LIB = PKG / "libgymrs_amd.so"
+
+# -ffp-contract=off: the shared physics header spells out every fma; nothing else may be fused,
+# or the GPU and its CPU f32 twin stop being bit-identical.
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fPIC",
+    "-shared",
+    "-Wall",
+    "-Wno-unused-function",
+]
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(d).stat().st_mtime <= t for d in deps)
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
+
+
+def _run(cmd, cwd=None):
+    print("+", " ".join(str(c) for c in cmd), flush=True)
+    subprocess.run([str(c) for c in cmd], cwd=cwd, check=True)
+
+
+def build_hip(force: bool = False) -> Path:
+    deps = HIP_SOURCES + HIP_HEADERS + [Path(__file__)]
+    if not force and _newer(LIB, deps):
+        return LIB
+    cmd = [_hipcc(), *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}", *HIP_SOURCES, "-o", LIB, "-ldl"]
+    _run(cmd)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> Path:
+    out = ORACLE / "build"
+    if force and out.exists():
+        shutil.rmtree(out)
+    _run(["make", "-C", str(ORACLE), "all"])
+    return out
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    force = "--force" in argv
+    build_hip(force)
+    build_oracle(force)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,767 @@
+// gymrs_engine.hip — host side of the C ABI (include/gymrs_amd.h): owns the SoA device buffers,
+// the HIP stream and the engine tick; every entry point cites the reference interface it
+// replaces in the header.  No CPU fallback exists: without a HIP device every call fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "gymrs_amd.h"
+#include "gymrs_kernels.h"
+
+using namespace gymrs;
+
+// ---------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static gymrs_status fail(gymrs_status st, const std::string& msg)
+{
+    g_last_error = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                                              \
+    do {                                                                                                           \
+        hipError_t err_ = (expr);                                                                                  \
+        if (err_ != hipSuccess)                                                                                    \
+            return fail(GYMRS_EHIP, std::string(#expr) + ": " + hipGetErrorString(err_));                          \
+    } while (0)
+
+// RCCL entry points, resolved at first use so that the stepping path has no hard RCCL dependency.
+struct NcclId128 { // ncclUniqueId (rccl.h): 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+    char internal[128];
+};
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId128, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+struct gymrs_engine {
+    gymrs_env_kind kind;
+    uint64_t n = 0, gid0 = 0;
+    int device = 0;
+    uint32_t flags = 0;
+    int vec = 4;
+    int state_dim = 0, obs_dim = 0;
+    union {
+        CartPoleConsts cp;
+        MountainCarConsts mc;
+        PendulumConsts pd;
+    } consts;
+    float max_torque = 2.0f;
+    float lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};         // current reset box
+    float dflt_lo[4] = {0, 0, 0, 0}, dflt_hi[4] = {0, 0, 0, 0}; // default reset box
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device buffers
+    float* s[4] = {nullptr, nullptr, nullptr, nullptr};
+    float* obs_cos = nullptr;
+    float* obs_sin = nullptr;
+    float* reward = nullptr;
+    uint8_t* done = nullptr;
+    uint8_t* truncated = nullptr;
+    uint8_t* beyond = nullptr;
+    uint32_t* ep_start = nullptr;
+    float* ep_ret = nullptr;
+    unsigned long long* block_stats = nullptr;
+    uint32_t n_stat_blocks = 0;
+    uint32_t* err = nullptr;
+    double* stats_dev = nullptr;
+    void* action_staging = nullptr; // for gymrs_step_host
+    uint64_t seed = 0, tick = 0;
+    double n_steps_total = 0;
+    void* comm = nullptr; // ncclComm_t
+    int n_ranks = 1;
+};
+
+static RcclApi g_rccl;
+
+static const void* consts_ptr(const gymrs_engine* e)
+{
+    switch (e->kind) {
+    case GYMRS_CARTPOLE: return &e->consts.cp;
+    case GYMRS_MOUNTAIN_CAR: return &e->consts.mc;
+    default: return &e->consts.pd;
+    }
+}
+
+static size_t action_size(gymrs_env_kind kind) { return kind == GYMRS_PENDULUM ? sizeof(float) : sizeof(uint8_t); }
+
+static uint64_t os_entropy()
+{
+    // seeding.rs:22 `thread_rng().gen()`: a fresh seed from the OS
+    std::random_device rd;
+    return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
+
+static StepArgs step_args(const gymrs_engine* e, const void* actions)
+{
+    StepArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < 4; ++j) a.s[j] = e->s[j];
+    a.obs_cos = e->obs_cos;
+    a.obs_sin = e->obs_sin;
+    a.action = actions;
+    a.reward = e->reward;
+    a.done = e->done;
+    a.truncated = e->truncated;
+    a.beyond = e->beyond;
+    a.ep_start = e->ep_start;
+    a.ep_ret = e->ep_ret;
+    a.block_stats = e->block_stats;
+    a.err = e->err;
+    a.n = e->n;
+    a.gid0 = e->gid0;
+    a.seed = e->seed;
+    a.tick = e->tick;
+    for (int j = 0; j < 4; ++j) {
+        a.lo[j] = e->lo[j];
+        a.hi[j] = e->hi[j];
+    }
+    return a;
+}
+
+template <class T>
+static gymrs_status dev_alloc(T** p, size_t count)
+{
+    void* q = nullptr;
+    hipError_t err = hipMalloc(&q, (count ? count : 1) * sizeof(T));
+    if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("hipMalloc: ") + hipGetErrorString(err));
+    *p = static_cast<T*>(q);
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* gymrs_last_error(void) { return g_last_error.c_str(); }
+int gymrs_abi_version(void) { return GYMRS_ABI_VERSION; }
+
+int gymrs_discrete_contains(uint64_t n, uint64_t value) { return value < n; } // discrete.rs:14-19
+
+gymrs_status gymrs_default_params(gymrs_env_kind kind, void* params)
+{
+    if (!params) return fail(GYMRS_EINVAL, "gymrs_default_params: params is NULL");
+    switch (kind) {
+    case GYMRS_CARTPOLE: {
+        auto* p = static_cast<gymrs_cartpole_params*>(params);
+        p->gravity = 9.8;
+        p->masscart = 1.0;
+        p->masspole = 0.1;
+        p->length = 0.5;
+        p->force_mag = 10.0;
+        p->tau = 0.02;
+        p->theta_threshold_radians = 12. * 2. * 3.14159265358979323846 / 360.;
+        p->x_threshold = 2.4;
+        p->kinematics_integrator = 0;
+        p->max_episode_steps = 500;
+        return GYMRS_OK;
+    }
+    case GYMRS_MOUNTAIN_CAR: {
+        auto* p = static_cast<gymrs_mountain_car_params*>(params);
+        p->min_position = -1.2;
+        p->max_position = 0.6;
+        p->max_speed = 0.07;
+        p->goal_position = 0.5;
+        p->goal_velocity = 0.;
+        p->force = 0.001;
+        p->gravity = 0.0025;
+        p->max_episode_steps = 200;
+        p->_pad = 0;
+        return GYMRS_OK;
+    }
+    case GYMRS_PENDULUM: {
+        auto* p = static_cast<gymrs_pendulum_params*>(params);
+        p->max_speed = 8.;
+        p->max_torque = 2.;
+        p->dt = 0.05;
+        p->g = 10.;
+        p->m = 1.;
+        p->l = 1.;
+        p->max_episode_steps = 200;
+        p->_pad = 0;
+        return GYMRS_OK;
+    }
+    }
+    return fail(GYMRS_EINVAL, "gymrs_default_params: unknown env kind");
+}
+
+gymrs_status gymrs_action_space(gymrs_env_kind kind, uint32_t* n, double* box_low, double* box_high)
+{
+    if (!n) return fail(GYMRS_EINVAL, "gymrs_action_space: n is NULL");
+    switch (kind) {
+    case GYMRS_CARTPOLE: *n = 2; break;     // cartpole.rs:114
+    case GYMRS_MOUNTAIN_CAR: *n = 3; break; // mountain_car.rs:362
+    case GYMRS_PENDULUM:
+        *n = 0;
+        if (box_low) *box_low = -2.0;
+        if (box_high) *box_high = 2.0;
+        break;
+    default: return fail(GYMRS_EINVAL, "gymrs_action_space: unknown env kind");
+    }
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_observation_space(gymrs_env_kind kind, const void* params, double* low, double* high, int* dim)
+{
+    if (!low || !high || !dim) return fail(GYMRS_EINVAL, "gymrs_observation_space: NULL output");
+    const double inf = std::numeric_limits<double>::infinity();
+    switch (kind) {
+    case GYMRS_CARTPOLE: {
+        gymrs_cartpole_params d;
+        gymrs_default_params(kind, &d);
+        const auto* p = params ? static_cast<const gymrs_cartpole_params*>(params) : &d;
+        // cartpole.rs:105-113: high = (2*x_thr, inf, 2*theta_thr, inf), low = -high
+        high[0] = p->x_threshold * 2.;
+        high[1] = inf;
+        high[2] = p->theta_threshold_radians * 2.;
+        high[3] = inf;
+        for (int j = 0; j < 4; ++j) low[j] = -high[j];
+        *dim = 4;
+        return GYMRS_OK;
+    }
+    case GYMRS_MOUNTAIN_CAR: {
+        gymrs_mountain_car_params d;
+        gymrs_default_params(kind, &d);
+        const auto* p = params ? static_cast<const gymrs_mountain_car_params*>(params) : &d;
+        // mountain_car.rs:353-354
+        low[0] = p->min_position;
+        low[1] = -p->max_speed;
+        high[0] = p->max_position;
+        high[1] = p->max_speed;
+        *dim = 2;
+        return GYMRS_OK;
+    }
+    case GYMRS_PENDULUM: {
+        gymrs_pendulum_params d;
+        gymrs_default_params(kind, &d);
+        const auto* p = params ? static_cast<const gymrs_pendulum_params*>(params) : &d;
+        low[0] = -1.;
+        low[1] = -1.;
+        low[2] = -p->max_speed;
+        high[0] = 1.;
+        high[1] = 1.;
+        high[2] = p->max_speed;
+        *dim = 3;
+        return GYMRS_OK;
+    }
+    }
+    return fail(GYMRS_EINVAL, "gymrs_observation_space: unknown env kind");
+}
+
+// ---------------------------------------------------------------------------------------------
+gymrs_status gymrs_engine_destroy(gymrs_engine* e)
+{
+    if (!e) return GYMRS_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    for (int j = 0; j < 4; ++j) (void)hipFree(e->s[j]);
+    (void)hipFree(e->obs_cos);
+    (void)hipFree(e->obs_sin);
+    (void)hipFree(e->reward);
+    (void)hipFree(e->done);
+    (void)hipFree(e->truncated);
+    (void)hipFree(e->beyond);
+    (void)hipFree(e->ep_start);
+    (void)hipFree(e->ep_ret);
+    (void)hipFree(e->block_stats);
+    (void)hipFree(e->err);
+    (void)hipFree(e->stats_dev);
+    (void)hipFree(e->action_staging);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t global_env_offset, int device,
+                                 const void* params, uint32_t flags, gymrs_engine** out)
+{
+    if (!out) return fail(GYMRS_EINVAL, "gymrs_engine_create: out is NULL");
+    *out = nullptr;
+    if (kind != GYMRS_CARTPOLE && kind != GYMRS_MOUNTAIN_CAR && kind != GYMRS_PENDULUM)
+        return fail(GYMRS_EINVAL, "gymrs_engine_create: unknown env kind");
+    if (n_envs == 0) return fail(GYMRS_EINVAL, "gymrs_engine_create: n_envs must be > 0");
+    if (n_envs > (1ull << 32)) return fail(GYMRS_EINVAL, "gymrs_engine_create: n_envs must be <= 2^32 per engine");
+    if (flags & ~(uint32_t)(GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT))
+        return fail(GYMRS_EINVAL, "gymrs_engine_create: unknown flag bits");
+    if ((flags & GYMRS_TRACK_STATS) && !(flags & GYMRS_AUTO_RESET))
+        return fail(GYMRS_EINVAL, "gymrs_engine_create: GYMRS_TRACK_STATS needs GYMRS_AUTO_RESET");
+    int n_dev = 0;
+    hipError_t derr = hipGetDeviceCount(&n_dev);
+    if (derr != hipSuccess || n_dev <= 0)
+        return fail(GYMRS_EHIP, std::string("gymrs_engine_create: no HIP device available (") +
+                                    (derr != hipSuccess ? hipGetErrorString(derr) : "device count 0") +
+                                    "); this library has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GYMRS_EINVAL, "gymrs_engine_create: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    gymrs_engine* e = new (std::nothrow) gymrs_engine();
+    if (!e) return fail(GYMRS_ENOMEM, "gymrs_engine_create: host allocation failed");
+    e->kind = kind;
+    e->n = n_envs;
+    e->gid0 = global_env_offset;
+    e->device = device;
+    e->flags = flags;
+    switch (kind) {
+    case GYMRS_CARTPOLE: {
+        gymrs_cartpole_params d;
+        gymrs_default_params(kind, &d);
+        e->consts.cp = make_consts(params ? *static_cast<const gymrs_cartpole_params*>(params) : d);
+        e->state_dim = 4;
+        e->obs_dim = 4;
+        for (int j = 0; j < 4; ++j) { // cartpole.rs:353-361
+            e->dflt_lo[j] = -0.05f;
+            e->dflt_hi[j] = 0.05f;
+        }
+        break;
+    }
+    case GYMRS_MOUNTAIN_CAR: {
+        gymrs_mountain_car_params d;
+        gymrs_default_params(kind, &d);
+        e->consts.mc = make_consts(params ? *static_cast<const gymrs_mountain_car_params*>(params) : d);
+        e->state_dim = 2;
+        e->obs_dim = 2;
+        e->dflt_lo[0] = -0.6f; // mountain_car.rs:176-187
+        e->dflt_hi[0] = -0.4f;
+        break;
+    }
+    case GYMRS_PENDULUM: {
+        gymrs_pendulum_params d;
+        gymrs_default_params(kind, &d);
+        const auto& p = params ? *static_cast<const gymrs_pendulum_params*>(params) : d;
+        e->consts.pd = make_consts(p);
+        e->max_torque = (float)p.max_torque;
+        e->state_dim = 2;
+        e->obs_dim = 3;
+        e->dflt_lo[0] = -kPiF;
+        e->dflt_hi[0] = kPiF;
+        e->dflt_lo[1] = -1.0f;
+        e->dflt_hi[1] = 1.0f;
+        break;
+    }
+    }
+    std::memcpy(e->lo, e->dflt_lo, sizeof(e->lo));
+    std::memcpy(e->hi, e->dflt_hi, sizeof(e->hi));
+
+    gymrs_status st = GYMRS_OK;
+    auto chk = [&](gymrs_status s_) {
+        if (st == GYMRS_OK) st = s_;
+    };
+    // Arrays are padded to a multiple of 16 lanes so the last vector access of the engine's own
+    // arrays stays inside the allocation; the caller's action buffer is never read past n.
+    const size_t npad = (size_t)((n_envs + 15) & ~15ull);
+    for (int j = 0; j < e->state_dim; ++j) chk(dev_alloc(&e->s[j], npad));
+    if (kind == GYMRS_PENDULUM) {
+        chk(dev_alloc(&e->obs_cos, npad));
+        chk(dev_alloc(&e->obs_sin, npad));
+        if (flags & GYMRS_TRACK_STATS) chk(dev_alloc(&e->ep_ret, npad));
+    }
+    chk(dev_alloc(&e->reward, npad));
+    chk(dev_alloc(&e->done, npad));
+    chk(dev_alloc(&e->truncated, npad));
+    chk(dev_alloc(&e->beyond, npad));
+    chk(dev_alloc(&e->ep_start, npad));
+    e->n_stat_blocks = step_grid(n_envs, 1);
+    chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 4));
+    chk(dev_alloc(&e->err, 2));
+    chk(dev_alloc(&e->stats_dev, 4));
+    if (st != GYMRS_OK) {
+        std::string msg = g_last_error;
+        gymrs_engine_destroy(e);
+        return fail(st, msg);
+    }
+    hipError_t serr = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (serr != hipSuccess) {
+        gymrs_engine_destroy(e);
+        return fail(GYMRS_EHIP, std::string("hipStreamCreate: ") + hipGetErrorString(serr));
+    }
+    e->own_stream = true;
+    static const uint32_t err_init[2] = {0u, 0xffffffffu};
+    hipError_t merr = hipMemcpyAsync(e->err, err_init, sizeof(err_init), hipMemcpyHostToDevice, e->stream);
+    if (merr == hipSuccess) merr = hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 4 * sizeof(unsigned long long), e->stream);
+    if (merr == hipSuccess) merr = hipMemsetAsync(e->truncated, 0, npad, e->stream);
+    if (merr == hipSuccess) merr = hipMemsetAsync(e->stats_dev, 0, 4 * sizeof(double), e->stream);
+    if (merr != hipSuccess) {
+        gymrs_engine_destroy(e);
+        return fail(GYMRS_EHIP, std::string("engine init: ") + hipGetErrorString(merr));
+    }
+    // ::new samples an initial state from an OS seed (cartpole.rs:92,120; mountain_car.rs:342,358)
+    st = gymrs_reset(e, 0, 0, nullptr, nullptr);
+    if (st == GYMRS_OK) st = gymrs_sync(e);
+    if (st != GYMRS_OK) {
+        std::string msg = g_last_error;
+        gymrs_engine_destroy(e);
+        return fail(st, msg);
+    }
+    *out = e;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_set_stream(gymrs_engine* e, void* hip_stream)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_set_stream: engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) HIP_TRY(hipStreamDestroy(e->stream));
+    e->stream = static_cast<hipStream_t>(hip_stream);
+    e->own_stream = false;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream)
+{
+    if (!e || !hip_stream) return fail(GYMRS_EINVAL, "gymrs_get_stream: NULL argument");
+    *hip_stream = e->stream;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
+    if (lanes_per_thread != 1 && lanes_per_thread != 2 && lanes_per_thread != 4)
+        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 1, 2 or 4");
+    e->vec = lanes_per_thread;
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const float* bounds, uint64_t* seed_used)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_reset: engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    float lo[4], hi[4];
+    std::memcpy(lo, e->dflt_lo, sizeof(lo));
+    std::memcpy(hi, e->dflt_hi, sizeof(hi));
+    if (bounds) {
+        // `options: Option<BoxR<Observation>>` (core.rs:49): state_dim lows then state_dim highs.
+        const int d = e->state_dim;
+        const int sampled = (e->kind == GYMRS_MOUNTAIN_CAR) ? 1 : d; // velocity is not sampled (mountain_car.rs:165)
+        for (int j = 0; j < sampled; ++j) {
+            lo[j] = bounds[j];
+            hi[j] = bounds[d + j];
+            // rand's Uniform::new panics unless low < high and both are finite [RECALLED]
+            if (!(lo[j] < hi[j]) || !std::isfinite(lo[j]) || !std::isfinite(hi[j]))
+                return fail(GYMRS_EINVAL, "gymrs_reset: bounds need finite low < high");
+        }
+    }
+    std::memcpy(e->lo, lo, sizeof(lo));
+    std::memcpy(e->hi, hi, sizeof(hi));
+    // seeding.rs:21-26: the generator is re-created on every reset
+    e->seed = has_seed ? seed : os_entropy();
+    e->tick = 0;
+    if (seed_used) *seed_used = e->seed;
+
+    ResetArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < 4; ++j) a.s[j] = e->s[j];
+    a.obs_cos = e->obs_cos;
+    a.obs_sin = e->obs_sin;
+    a.reward = e->reward;
+    a.done = e->done;
+    a.truncated = e->truncated;
+    a.beyond = e->beyond;
+    a.ep_start = e->ep_start;
+    a.ep_ret = e->ep_ret;
+    a.n = e->n;
+    a.gid0 = e->gid0;
+    a.seed = e->seed;
+    a.tick = e->tick;
+    for (int j = 0; j < 4; ++j) {
+        a.lo[j] = lo[j];
+        a.hi[j] = hi[j];
+    }
+    HIP_TRY(launch_reset(e->kind, a, e->stream));
+    e->tick += 1;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
+{
+    if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    StepArgs a = step_args(e, actions_dev);
+    HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
+    e->tick += 1;
+    e->n_steps_total += (double)e->n;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host)
+{
+    if (!e || !actions_host) return fail(GYMRS_EINVAL, "gymrs_step_host: NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t bytes = (size_t)e->n * action_size(e->kind);
+    if (!e->action_staging) HIP_TRY(hipMalloc(&e->action_staging, ((bytes + 63) & ~(size_t)63)));
+    HIP_TRY(hipMemcpyAsync(e->action_staging, actions_host, bytes, hipMemcpyHostToDevice, e->stream));
+    return gymrs_step(e, e->action_staging);
+}
+
+gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes, uint32_t n_buffers,
+                             uint32_t n_steps, int use_graph)
+{
+    if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step_many: NULL argument");
+    if (n_buffers == 0) return fail(GYMRS_EINVAL, "gymrs_step_many: n_buffers must be > 0");
+    if (use_graph) return fail(GYMRS_EINVAL, "gymrs_step_many: use_graph is reserved (must be 0)");
+    HIP_TRY(hipSetDevice(e->device));
+    const char* base = static_cast<const char*>(actions_dev);
+    for (uint32_t t = 0; t < n_steps; ++t) {
+        StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
+        HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
+        e->tick += 1;
+    }
+    e->n_steps_total += (double)e->n * (double)n_steps;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_sync(gymrs_engine* e)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    uint32_t err[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(err, e->err, sizeof(err), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (err[0] != 0) {
+        static const uint32_t err_init[2] = {0u, 0xffffffffu};
+        HIP_TRY(hipMemcpyAsync(e->err, err_init, sizeof(err_init), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        char buf[160];
+        std::snprintf(buf, sizeof(buf), "%u invalid action(s); first offending lane %u (usize invalid)", err[0], err[1]);
+        return fail(GYMRS_EACTION, buf);
+    }
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+gymrs_status gymrs_obs_ptrs(gymrs_engine* e, float** out_ptrs, int* obs_dim)
+{
+    if (!e || !out_ptrs || !obs_dim) return fail(GYMRS_EINVAL, "gymrs_obs_ptrs: NULL argument");
+    if (e->kind == GYMRS_PENDULUM) {
+        out_ptrs[0] = e->obs_cos;
+        out_ptrs[1] = e->obs_sin;
+        out_ptrs[2] = e->s[1]; // theta_dot: the observation column IS the state column
+    } else {
+        for (int j = 0; j < e->obs_dim; ++j) out_ptrs[j] = e->s[j];
+    }
+    *obs_dim = e->obs_dim;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_state_ptrs(gymrs_engine* e, float** out_ptrs, int* state_dim)
+{
+    if (!e || !out_ptrs || !state_dim) return fail(GYMRS_EINVAL, "gymrs_state_ptrs: NULL argument");
+    for (int j = 0; j < e->state_dim; ++j) out_ptrs[j] = e->s[j];
+    *state_dim = e->state_dim;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_reward_ptr(gymrs_engine* e, float** out)
+{
+    if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_reward_ptr: NULL argument");
+    *out = e->reward;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_done_ptr(gymrs_engine* e, uint8_t** out)
+{
+    if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_done_ptr: NULL argument");
+    *out = e->done;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_truncated_ptr(gymrs_engine* e, uint8_t** out)
+{
+    if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_truncated_ptr: NULL argument");
+    *out = e->truncated;
+    return GYMRS_OK;
+}
+
+static gymrs_status range_check(const gymrs_engine* e, uint64_t first, uint64_t count, const char* who)
+{
+    if (first > e->n || count > e->n - first) return fail(GYMRS_EINVAL, std::string(who) + ": lane range out of bounds");
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_obs(gymrs_engine* e, uint64_t first, uint64_t count, float* host_out)
+{
+    if (!e || !host_out) return fail(GYMRS_EINVAL, "gymrs_get_obs: NULL argument");
+    if (gymrs_status st = range_check(e, first, count, "gymrs_get_obs")) return st;
+    HIP_TRY(hipSetDevice(e->device));
+    float* ptrs[4];
+    int dim = 0;
+    gymrs_obs_ptrs(e, ptrs, &dim);
+    for (int j = 0; j < dim; ++j)
+        HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, ptrs[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_state(gymrs_engine* e, uint64_t first, uint64_t count, float* host_out)
+{
+    if (!e || !host_out) return fail(GYMRS_EINVAL, "gymrs_get_state: NULL argument");
+    if (gymrs_status st = range_check(e, first, count, "gymrs_get_state")) return st;
+    HIP_TRY(hipSetDevice(e->device));
+    for (int j = 0; j < e->state_dim; ++j)
+        HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, e->s[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_set_state(gymrs_engine* e, uint64_t first, uint64_t count, const float* host_in)
+{
+    if (!e || !host_in) return fail(GYMRS_EINVAL, "gymrs_set_state: NULL argument");
+    if (gymrs_status st = range_check(e, first, count, "gymrs_set_state")) return st;
+    HIP_TRY(hipSetDevice(e->device));
+    for (int j = 0; j < e->state_dim; ++j)
+        HIP_TRY(hipMemcpyAsync(e->s[j] + first, host_in + (size_t)j * count, count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    // assigning `env.state` in the reference leaves steps_beyond_terminated alone; a fresh state
+    // here starts a fresh episode, which is what every caller of a batched set_state wants.
+    HIP_TRY(launch_clear_beyond_range(e->beyond, e->ep_start, first, count, (uint32_t)e->tick, e->stream));
+    if (e->kind == GYMRS_PENDULUM) {
+        // keep the observation columns consistent with the new state
+        std::vector<float> c(count), s(count);
+        for (uint64_t i = 0; i < count; ++i) sincosf_(host_in[i], &s[i], &c[i]);
+        HIP_TRY(hipMemcpyAsync(e->obs_cos + first, c.data(), count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->obs_sin + first, s.data(), count * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t count, float* reward, uint8_t* done,
+                                   uint8_t* truncated)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_get_step_result: engine is NULL");
+    if (gymrs_status st = range_check(e, first, count, "gymrs_get_step_result")) return st;
+    HIP_TRY(hipSetDevice(e->device));
+    if (reward) HIP_TRY(hipMemcpyAsync(reward, e->reward + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (done) HIP_TRY(hipMemcpyAsync(done, e->done + first, count, hipMemcpyDeviceToHost, e->stream));
+    if (truncated) HIP_TRY(hipMemcpyAsync(truncated, e->truncated + first, count, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+gymrs_status gymrs_stats_device(gymrs_engine* e, double** dev_out4)
+{
+    if (!e || !dev_out4) return fail(GYMRS_EINVAL, "gymrs_stats_device: NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_stats_reduce(e->block_stats, e->n_stat_blocks, e->n_steps_total, e->stats_dev, e->stream));
+    *dev_out4 = e->stats_dev;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_stats(gymrs_engine* e, double out[4])
+{
+    if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_stats: NULL argument");
+    double* dev = nullptr;
+    if (gymrs_status st = gymrs_stats_device(e, &dev)) return st;
+    HIP_TRY(hipMemcpyAsync(out, dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_stats_clear(gymrs_engine* e)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_stats_clear: engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 4 * sizeof(unsigned long long), e->stream));
+    e->n_steps_total = 0;
+    return GYMRS_OK;
+}
+
+// ---- RCCL (one process per GPU; ncclAllReduce of 4 doubles over xGMI) --------------------------
+static gymrs_status rccl_load()
+{
+    if (g_rccl.lib) return GYMRS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* nm : names) {
+        lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (lib) break;
+    }
+    if (!lib) return fail(GYMRS_ENCCL, std::string("cannot load librccl: ") + dlerror());
+    RcclApi api;
+    api.lib = lib;
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
+        return fail(GYMRS_ENCCL, "librccl lacks an expected nccl* symbol");
+    g_rccl = api;
+    return GYMRS_OK;
+}
+
+static gymrs_status nccl_fail(const char* what, int rc)
+{
+    return fail(GYMRS_ENCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"));
+}
+
+gymrs_status gymrs_comm_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return fail(GYMRS_EINVAL, "gymrs_comm_unique_id: NULL argument");
+    if (gymrs_status st = rccl_load()) return st;
+    if (int rc = g_rccl.GetUniqueId(id_out)) return nccl_fail("ncclGetUniqueId", rc);
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_comm_init(gymrs_engine* e, int n_ranks, int rank, const uint8_t id[128])
+{
+    if (!e || !id) return fail(GYMRS_EINVAL, "gymrs_comm_init: NULL argument");
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(GYMRS_EINVAL, "gymrs_comm_init: bad rank / n_ranks");
+    if (gymrs_status st = rccl_load()) return st;
+    HIP_TRY(hipSetDevice(e->device));
+    NcclId128 uid;
+    std::memcpy(uid.internal, id, 128);
+    if (int rc = g_rccl.CommInitRank(&e->comm, n_ranks, uid, rank)) return nccl_fail("ncclCommInitRank", rc);
+    e->n_ranks = n_ranks;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4])
+{
+    if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats: NULL argument");
+    if (!e->comm) return fail(GYMRS_ENCCL, "gymrs_allreduce_stats: call gymrs_comm_init first");
+    double* dev = nullptr;
+    if (gymrs_status st = gymrs_stats_device(e, &dev)) return st;
+    // ncclFloat64 = 8, ncclSum = 0 (rccl.h); 32 bytes per rank: latency-bound, rides the engine stream
+    if (int rc = g_rccl.AllReduce(dev, dev, 4, 8, 0, e->comm, e->stream)) return nccl_fail("ncclAllReduce", rc);
+    HIP_TRY(hipMemcpyAsync(out, dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t seed, uint64_t t)
+{
+    if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_fill_actions: NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(launch_fill_actions(e->kind, actions_dev, e->n, e->gid0, seed, t, e->max_torque, e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_get_tick: engine is NULL");
+    if (tick) *tick = e->tick;
+    if (seed) *seed = e->seed;
+    return GYMRS_OK;
+}
+
+} // extern "C"

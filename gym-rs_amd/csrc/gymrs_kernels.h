@@ -1,0 +1,61 @@
+// gymrs_kernels.h — launch interface between the engine (gymrs_engine.hip) and the gfx950 kernels
+// (gymrs_kernels.hip).  Plain structs passed by value as kernel arguments (uniform -> SGPRs).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gymrs_physics.h"
+
+namespace gymrs {
+
+constexpr int kBlock = 256; // 4 wavefronts of 64
+
+// Everything one step() launch needs.  Device pointers are SoA arrays of n lanes.
+struct StepArgs {
+    float* s[4];       // state: CartPole x,x_dot,theta,theta_dot | MountainCar position,velocity | Pendulum theta,theta_dot
+    float* obs_cos;    // Pendulum only
+    float* obs_sin;    // Pendulum only
+    const void* action; // u8 (CartPole, MountainCar) or f32 (Pendulum)
+    float* reward;
+    uint8_t* done;
+    uint8_t* truncated; // written only with GYMRS_TIME_LIMIT
+    uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
+    uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
+    float* ep_ret;      // Pendulum with GYMRS_TRACK_STATS: running episode return
+    unsigned long long* block_stats; // [n_blocks][4]: n_episodes, sum_length, sum_return (f64 bits), unused
+    uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1
+    uint64_t n;         // lanes in this engine
+    uint64_t gid0;      // global id of lane 0
+    uint64_t seed;
+    uint64_t tick;
+    float lo[4], hi[4]; // reset sampling box
+};
+
+struct ResetArgs {
+    float* s[4];
+    float* obs_cos;
+    float* obs_sin;
+    float* reward;
+    uint8_t* done;
+    uint8_t* truncated;
+    uint8_t* beyond;
+    uint32_t* ep_start;
+    float* ep_ret;
+    uint64_t n, gid0, seed, tick;
+    float lo[4], hi[4];
+};
+
+// Number of workgroups step_kernel uses for n lanes at `vec` lanes per work-item.
+inline uint32_t step_grid(uint64_t n, int vec) { return (uint32_t)((n + (uint64_t)kBlock * vec - 1) / ((uint64_t)kBlock * vec)); }
+
+hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
+                       hipStream_t stream);
+hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
+hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
+                               float max_torque, hipStream_t stream);
+// out4 = {sum_return, sum_length, n_episodes, n_steps}
+hipError_t launch_stats_reduce(const unsigned long long* block_stats, uint32_t n_blocks, double n_steps, double* out4,
+                               hipStream_t stream);
+hipError_t launch_clear_beyond_range(uint8_t* beyond, uint32_t* ep_start, uint64_t first, uint64_t count, uint32_t tick,
+                                     hipStream_t stream);
+
+} // namespace gymrs

@@ -1,0 +1,71 @@
+// gymrs_philox.h — hand-written Philox4x32-10 (Salmon et al., SC'11) for reset sampling.
+//
+// Replaces the reference's reset RNG chain
+//   seeding::rand_random -> Pcg64::seed_from_u64      /root/reference/src/utils/seeding.rs:21-26
+//   Uniform::new(low, high).sample(rng)               cartpole.rs:363, mountain_car.rs:189
+// with a counter-based generator (north_star): a lane's draw is a pure function of
+// (seed, global env id, tick), so results do not depend on how lanes are sharded over GPUs,
+// and there is no per-lane generator state to keep in HBM.  The reference re-creates its PRNG on
+// every reset(), so no reference behaviour depends on stream continuity.
+//
+// Counter layout (same in oracle/gymrs_oracle.c, which restates it independently):
+//   key     = (seed lo, seed hi)
+//   counter = (gid lo, gid hi, tick lo, (tick hi & 0xffff) | stream << 16)
+//   stream 0 = reset sampling, stream 1 = synthetic action generation (bench / tests)
+#pragma once
+#include "gymrs_math.h"
+
+namespace gymrs {
+
+struct u32x4 {
+    uint32_t v[4];
+};
+
+constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
+constexpr uint32_t kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
+
+GYMRS_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int round = 0; round < 10; ++round) {
+        uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
+        uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += kPhiloxW0;
+        k1 += kPhiloxW1;
+    }
+    return u32x4{{c0, c1, c2, c3}};
+}
+
+constexpr uint32_t kStreamReset = 0, kStreamAction = 1;
+
+GYMRS_HD u32x4 draw4(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t stream)
+{
+    return philox4x32_10((uint32_t)gid, (uint32_t)(gid >> 32), (uint32_t)tick,
+                         ((uint32_t)(tick >> 32) & 0xffffu) | (stream << 16), (uint32_t)seed,
+                         (uint32_t)(seed >> 32));
+}
+
+// u32 -> uniform f32 on [low, high): 24 random bits, u*scale + low, guarded to stay below high
+// (half-open like rand's Uniform::new, cartpole.rs:363).
+GYMRS_HD float uniform_between(uint32_t r, float low, float high)
+{
+    float u = (float)(r >> 8) * 0x1p-24f;
+    float v = fmaf_(u, high - low, low);
+    if (!(v < high)) {
+        // largest float below high (high is finite and low < high)
+        uint32_t h = f2u(high);
+        h = (high > 0.0f) ? h - 1u : ((h & 0x7fffffffu) == 0u ? 0x80000001u : h + 1u);
+        v = u2f(h);
+    }
+    return v;
+}
+
+} // namespace gymrs

@@ -1,0 +1,211 @@
+// gymrs_physics.h — per-lane f32 physics of the gym-rs classic-control envs, shared by the HIP
+// kernels (device) and the host (CPU f32 twin used by the tests for bit-exact comparison).
+//
+// Restates, in f32 and per lane:
+//   CartPoleEnv::step      /root/reference/src/envs/classical_control/cartpole.rs:398-483
+//   MountainCarEnv::step   /root/reference/src/envs/classical_control/mountain_car.rs:398-435
+//   clip                   /root/reference/src/utils/custom/util_fns.rs:2-10
+//   reset sampling order   cartpole.rs:317-324,352-364 ; mountain_car.rs:162-167,175-190
+//   Pendulum: spec-derived (Gym Pendulum-v1); NOT in the reference.
+//
+// Arithmetic contract (what "the f32 twin" means): IEEE f32, round-to-nearest, denormals kept,
+// -ffp-contract=off on both compilers; a*b+c is fused ONLY where fmaf_ is written.  Divisions are
+// IEEE-correct on both sides (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+// sin/cos come from gymrs_math.h.  With that, gfx950 and x86 produce identical bits.
+#pragma once
+#include "gymrs_amd.h"
+#include "gymrs_math.h"
+#include "gymrs_philox.h"
+
+namespace gymrs {
+
+// ---------------------------------------------------------------------------------------------
+// clip (util_fns.rs:2-10) with OrderedFloat's total order (NaN is the maximum):
+//   l <= v && v <= r -> v ; v > r -> r ; else l.   NaN fails `v <= r` and is `> r`, so -> r.
+GYMRS_HD float clipf(float v, float l, float r)
+{
+    if (!(v <= r)) return r;
+    if (!(v >= l)) return l;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CartPole
+struct CartPoleConsts {
+    float gravity, masspole, length, force_mag, tau;
+    float total_mass;      // masspole + masscart          cartpole.rs:146-148
+    float polemass_length; // masspole + length (sic, Q1)  cartpole.rs:150-152
+    float four_thirds;     // 4.0/3.0                      cartpole.rs:427
+    float theta_thr, x_thr;
+    int32_t integrator;    // 0 Euler, 1 Other             cartpole.rs:380-387
+    uint32_t max_steps;
+};
+
+inline CartPoleConsts make_consts(const gymrs_cartpole_params& p)
+{
+    CartPoleConsts c;
+    c.gravity = (float)p.gravity;
+    c.masspole = (float)p.masspole;
+    c.length = (float)p.length;
+    c.force_mag = (float)p.force_mag;
+    c.tau = (float)p.tau;
+    c.total_mass = (float)(p.masspole + p.masscart);
+    c.polemass_length = (float)(p.masspole + p.length); // the reference ADDS; do not "fix"
+    c.four_thirds = (float)(4.0 / 3.0);
+    c.theta_thr = (float)p.theta_threshold_radians;
+    c.x_thr = (float)p.x_threshold;
+    c.integrator = p.kinematics_integrator;
+    c.max_steps = p.max_episode_steps ? p.max_episode_steps : 500u;
+    return c;
+}
+
+// One step of the dynamics + termination test.  Returns done.  (cartpole.rs:408-453)
+GYMRS_HD bool cartpole_advance(const CartPoleConsts& c, float& x, float& x_dot, float& theta, float& theta_dot,
+                               uint32_t action)
+{
+    const float force = (action == 1u) ? c.force_mag : -c.force_mag; // :414-418
+    float sintheta, costheta;
+    sincosf_(theta, &sintheta, &costheta); // :420-421
+    // :423-424  temp = (force + polemass_length * theta_dot^2 * sintheta) / total_mass
+    const float temp = fmaf_(c.polemass_length * (theta_dot * theta_dot), sintheta, force) / c.total_mass;
+    // :425-428  thetaacc = (g*sin - cos*temp) / (length * (4/3 - masspole*cos^2/total_mass))
+    const float num = fmaf_(-costheta, temp, c.gravity * sintheta);
+    const float den = c.length * (c.four_thirds - (c.masspole * (costheta * costheta)) / c.total_mass);
+    const float thetaacc = num / den;
+    // :429  xacc = temp - polemass_length * thetaacc * costheta / total_mass
+    const float xacc = temp - ((c.polemass_length * thetaacc) * costheta) / c.total_mass;
+    if (c.integrator == 0) { // :431-435 Euler: x and theta advance with the OLD velocities
+        x = fmaf_(c.tau, x_dot, x);
+        x_dot = fmaf_(c.tau, xacc, x_dot);
+        theta = fmaf_(c.tau, theta_dot, theta);
+        theta_dot = fmaf_(c.tau, thetaacc, theta_dot);
+    } else { // :436-441 semi-implicit
+        x_dot = fmaf_(c.tau, xacc, x_dot);
+        x = fmaf_(c.tau, x_dot, x);
+        theta_dot = fmaf_(c.tau, thetaacc, theta_dot);
+        theta = fmaf_(c.tau, theta_dot, theta);
+    }
+    // :450-453 strict compares; a NaN counts as "> threshold" in OrderedFloat's order (Q10)
+    return !(fabsf_(x) <= c.x_thr) || !(fabsf_(theta) <= c.theta_thr);
+}
+
+// :455-464 — reward with steps_beyond_terminated (`beyond` = is_some()).
+GYMRS_HD float cartpole_reward(bool done, bool& beyond)
+{
+    if (!done) return 1.0f;
+    if (!beyond) {
+        beyond = true;
+        return 1.0f;
+    }
+    return 0.0f;
+}
+
+// cartpole.rs:317-324: x, x_dot, theta, theta_dot in this order, each on [low, high).
+GYMRS_HD void cartpole_sample(const u32x4& r, const float* lo, const float* hi, float& x, float& x_dot, float& theta,
+                              float& theta_dot)
+{
+    x = uniform_between(r.v[0], lo[0], hi[0]);
+    x_dot = uniform_between(r.v[1], lo[1], hi[1]);
+    theta = uniform_between(r.v[2], lo[2], hi[2]);
+    theta_dot = uniform_between(r.v[3], lo[3], hi[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// MountainCar
+struct MountainCarConsts {
+    float min_position, max_position, max_speed, goal_position, goal_velocity, force, gravity;
+    uint32_t max_steps;
+};
+
+inline MountainCarConsts make_consts(const gymrs_mountain_car_params& p)
+{
+    MountainCarConsts c;
+    c.min_position = (float)p.min_position;
+    c.max_position = (float)p.max_position;
+    c.max_speed = (float)p.max_speed;
+    c.goal_position = (float)p.goal_position;
+    c.goal_velocity = (float)p.goal_velocity;
+    c.force = (float)p.force;
+    c.gravity = (float)p.gravity;
+    c.max_steps = p.max_episode_steps ? p.max_episode_steps : 200u;
+    return c;
+}
+
+// mountain_car.rs:408-423.  Returns done.
+GYMRS_HD bool mountain_car_advance(const MountainCarConsts& c, float& position, float& velocity, uint32_t action)
+{
+    // :411-412  velocity += (action - 1) * force + cos(3 * position) * (-gravity)
+    const float push = ((float)action - 1.0f) * c.force;
+    velocity = velocity + fmaf_(cosf_(3.0f * position), -c.gravity, push);
+    velocity = clipf(velocity, -c.max_speed, c.max_speed); // :413
+    position = position + velocity;                        // :415
+    position = clipf(position, c.min_position, c.max_position); // :416
+    // :418-420 exact equality with the clip bound (Q11)
+    if (position == c.min_position && velocity < 0.0f) velocity = 0.0f;
+    // :422 inclusive; NaN >= anything in OrderedFloat's order
+    return !(position < c.goal_position) && !(velocity < c.goal_velocity);
+}
+
+// mountain_car.rs:162-167: one draw for position, velocity exactly 0.
+GYMRS_HD void mountain_car_sample(const u32x4& r, const float* lo, const float* hi, float& position, float& velocity)
+{
+    position = uniform_between(r.v[0], lo[0], hi[0]);
+    velocity = 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pendulum (spec-derived; not in the reference)
+struct PendulumConsts {
+    float max_speed, max_torque, dt;
+    float c_sin; // 3*g/(2*l)
+    float c_u;   // 3/(m*l^2)
+    uint32_t max_steps;
+};
+
+inline PendulumConsts make_consts(const gymrs_pendulum_params& p)
+{
+    PendulumConsts c;
+    c.max_speed = (float)p.max_speed;
+    c.max_torque = (float)p.max_torque;
+    c.dt = (float)p.dt;
+    c.c_sin = (float)(3. * p.g / (2. * p.l));
+    c.c_u = (float)(3. / (p.m * (p.l * p.l)));
+    c.max_steps = p.max_episode_steps ? p.max_episode_steps : 200u;
+    return c;
+}
+
+// ((x + pi) mod 2pi) - pi with a floored modulo, evaluated in f64 so that the wrap point does
+// not add f32 error to angles tens of radians away from zero.
+GYMRS_HD float angle_normalize(float x)
+{
+    const double pi = 0x1.921fb54442d18p+1, two_pi = 0x1.921fb54442d18p+2, inv_two_pi = 0x1.45f306dc9c883p-3;
+    double y = (double)x + pi;
+    double q = __builtin_floor(y * inv_two_pi);
+    double m = fma_(-q, two_pi, y);
+    return (float)(m - pi);
+}
+
+// Returns the reward (-cost, from the OLD state); never terminates.
+GYMRS_HD float pendulum_advance(const PendulumConsts& c, float& theta, float& theta_dot, float action)
+{
+    const float u = clipf(action, -c.max_torque, c.max_torque);
+    const float an = angle_normalize(theta);
+    const float cost = fmaf_(0.001f, u * u, fmaf_(0.1f, theta_dot * theta_dot, an * an));
+    const float acc = fmaf_(c.c_sin, sinf_(theta), c.c_u * u);
+    float nthd = fmaf_(acc, c.dt, theta_dot);
+    nthd = clipf(nthd, -c.max_speed, c.max_speed);
+    theta = fmaf_(nthd, c.dt, theta); // semi-implicit: uses the NEW theta_dot
+    theta_dot = nthd;
+    return -cost;
+}
+
+GYMRS_HD void pendulum_sample(const u32x4& r, const float* lo, const float* hi, float& theta, float& theta_dot)
+{
+    theta = uniform_between(r.v[0], lo[0], hi[0]);
+    theta_dot = uniform_between(r.v[1], lo[1], hi[1]);
+}
+
+// Default reset boxes (obs_dim lows then highs in the API; here split).
+constexpr float kPiF = 3.14159274101257324f; // fl32(pi); the box is [-fl32(pi), fl32(pi))
+
+} // namespace gymrs

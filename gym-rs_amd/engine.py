@@ -1,0 +1,277 @@
+"""BatchedEngine — N independent gym-rs envs stepped by one HIP kernel launch.
+
+Thin ctypes binding over the C ABI (``include/gymrs_amd.h``).  The batched form of the reference
+API: ``step(actions)`` fills device arrays ``obs`` / ``reward`` / ``done`` / ``truncated``
+(``ActionReward``, core.rs:94-106) for every lane; ``reset(seed, options)`` is ``Env::reset``
+(core.rs:45-50) for every lane.  numpy is used only to hand host buffers across the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import load_library
+
+CARTPOLE, MOUNTAIN_CAR, PENDULUM = 0, 1, 2
+AUTO_RESET, TRACK_STATS, TIME_LIMIT = 1, 2, 4
+
+_OK, _EINVAL, _EHIP, _ENCCL, _ENOMEM, _EACTION = range(6)
+
+
+class GymrsError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"gymrs status {status}: {message}")
+        self.status = status
+
+
+class InvalidActionError(GymrsError, AssertionError):
+    """An action outside the action space: the reference's ``assert!`` panic (cartpole.rs:402-406)."""
+
+
+class CartPoleParams(C.Structure):
+    """The ``pub`` physics fields of ``CartPoleEnv`` (cartpole.rs:53-82)."""
+
+    _fields_ = [
+        ("gravity", C.c_double), ("masscart", C.c_double), ("masspole", C.c_double), ("length", C.c_double),
+        ("force_mag", C.c_double), ("tau", C.c_double), ("theta_threshold_radians", C.c_double),
+        ("x_threshold", C.c_double), ("kinematics_integrator", C.c_int32), ("max_episode_steps", C.c_uint32),
+    ]
+
+
+class MountainCarParams(C.Structure):
+    """The ``pub`` physics fields of ``MountainCarEnv`` (mountain_car.rs:49-77)."""
+
+    _fields_ = [
+        ("min_position", C.c_double), ("max_position", C.c_double), ("max_speed", C.c_double),
+        ("goal_position", C.c_double), ("goal_velocity", C.c_double), ("force", C.c_double),
+        ("gravity", C.c_double), ("max_episode_steps", C.c_uint32), ("_pad", C.c_uint32),
+    ]
+
+
+class PendulumParams(C.Structure):
+    """Gym Pendulum-v1 constants (spec-derived; not in the reference)."""
+
+    _fields_ = [
+        ("max_speed", C.c_double), ("max_torque", C.c_double), ("dt", C.c_double), ("g", C.c_double),
+        ("m", C.c_double), ("l", C.c_double), ("max_episode_steps", C.c_uint32), ("_pad", C.c_uint32),
+    ]
+
+
+_PARAMS = {CARTPOLE: CartPoleParams, MOUNTAIN_CAR: MountainCarParams, PENDULUM: PendulumParams}
+_STATE_DIM = {CARTPOLE: 4, MOUNTAIN_CAR: 2, PENDULUM: 2}
+_OBS_DIM = {CARTPOLE: 4, MOUNTAIN_CAR: 2, PENDULUM: 3}
+_ACTION_DTYPE = {CARTPOLE: np.uint8, MOUNTAIN_CAR: np.uint8, PENDULUM: np.float32}
+
+
+def default_params(kind: int):
+    lib = load_library()
+    p = _PARAMS[kind]()
+    _check(lib, lib.gymrs_default_params(kind, C.byref(p)))
+    return p
+
+
+def _check(lib, status: int) -> None:
+    if status == _OK:
+        return
+    msg = lib.gymrs_last_error().decode("utf-8", "replace")
+    if status == _EACTION:
+        raise InvalidActionError(status, msg)
+    raise GymrsError(status, msg)
+
+
+def shard_range(n_total: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous lane shard of rank ``rank``: (global offset, count).  Lanes are independent, so
+    the batch shards trivially; the global id keeps Philox draws identical for any world size."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, rem = divmod(n_total, world_size)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+class BatchedEngine:
+    """One engine = one shard of lanes on one GPU, driven by one host thread."""
+
+    def __init__(self, kind: int, n_envs: int, *, global_env_offset: int = 0, device: int = 0, params=None,
+                 flags: int = 0, lanes_per_thread: Optional[int] = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.kind = int(kind)
+        self.n_envs = int(n_envs)
+        self.global_env_offset = int(global_env_offset)
+        self.flags = int(flags)
+        self.state_dim = _STATE_DIM[self.kind]
+        self.obs_dim = _OBS_DIM[self.kind]
+        self.action_dtype = _ACTION_DTYPE[self.kind]
+        self.params = params if params is not None else default_params(self.kind)
+        _check(self._lib, self._lib.gymrs_engine_create(self.kind, self.n_envs, self.global_env_offset, int(device),
+                                                        C.byref(self.params), self.flags, C.byref(self._h)))
+        if lanes_per_thread is not None:
+            self.set_tuning(lanes_per_thread)
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        """``Env::close`` (core.rs:56)."""
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.gymrs_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- stream / tuning ----------------------------------------------------------------------
+    @property
+    def stream(self) -> int:
+        p = C.c_void_p()
+        _check(self._lib, self._lib.gymrs_get_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def set_stream(self, hip_stream: int) -> None:
+        _check(self._lib, self._lib.gymrs_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_tuning(self, lanes_per_thread: int) -> None:
+        _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), 0))
+
+    # -- Env::reset ------------------------------------------------------------------------------
+    def reset(self, seed: Optional[int] = None, options: Optional[Sequence[float]] = None) -> int:
+        """``reset(seed, _, options)`` for every lane.  ``options`` = state_dim lows then state_dim
+        highs.  Returns the seed number used (seeding.rs:21-26)."""
+        bounds = None
+        if options is not None:
+            arr = np.ascontiguousarray(options, dtype=np.float32)
+            if arr.size != 2 * self.state_dim:
+                raise ValueError(f"options needs {2 * self.state_dim} floats (lows then highs)")
+            bounds = arr.ctypes.data_as(C.POINTER(C.c_float))
+        used = C.c_uint64()
+        _check(self._lib, self._lib.gymrs_reset(self._h, 0 if seed is None else 1, 0 if seed is None else int(seed),
+                                                bounds, C.byref(used)))
+        return used.value
+
+    # -- Env::step ---------------------------------------------------------------------------------
+    def step(self, actions_dev: int) -> None:
+        """Asynchronous; ``actions_dev`` is a device address of n_envs actions."""
+        _check(self._lib, self._lib.gymrs_step(self._h, C.c_void_p(actions_dev)))
+
+    def step_host(self, actions) -> None:
+        a = np.ascontiguousarray(actions, dtype=self.action_dtype)
+        if a.size != self.n_envs:
+            raise ValueError("one action per lane expected")
+        _check(self._lib, self._lib.gymrs_step_host(self._h, a.ctypes.data_as(C.c_void_p)))
+        self.sync()  # the host buffer must outlive the copy
+
+    def step_many(self, actions_dev: int, stride_bytes: int, n_buffers: int, n_steps: int, use_graph: bool = False) -> None:
+        _check(self._lib, self._lib.gymrs_step_many(self._h, C.c_void_p(actions_dev), int(stride_bytes), int(n_buffers),
+                                                    int(n_steps), 1 if use_graph else 0))
+
+    def sync(self) -> None:
+        _check(self._lib, self._lib.gymrs_sync(self._h))
+
+    # -- device views -----------------------------------------------------------------------------
+    def obs_ptrs(self):
+        ptrs = (C.c_void_p * 4)()
+        dim = C.c_int()
+        _check(self._lib, self._lib.gymrs_obs_ptrs(self._h, ptrs, C.byref(dim)))
+        return [ptrs[j] for j in range(dim.value)]
+
+    def state_ptrs(self):
+        ptrs = (C.c_void_p * 4)()
+        dim = C.c_int()
+        _check(self._lib, self._lib.gymrs_state_ptrs(self._h, ptrs, C.byref(dim)))
+        return [ptrs[j] for j in range(dim.value)]
+
+    def _ptr(self, fn) -> int:
+        p = C.c_void_p()
+        _check(self._lib, fn(self._h, C.byref(p)))
+        return p.value or 0
+
+    @property
+    def reward_ptr(self) -> int:
+        return self._ptr(self._lib.gymrs_reward_ptr)
+
+    @property
+    def done_ptr(self) -> int:
+        return self._ptr(self._lib.gymrs_done_ptr)
+
+    @property
+    def truncated_ptr(self) -> int:
+        return self._ptr(self._lib.gymrs_truncated_ptr)
+
+    # -- host copies ---------------------------------------------------------------------------------
+    def get_obs(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n_envs - first if count is None else count
+        out = np.empty((self.obs_dim, count), dtype=np.float32)
+        _check(self._lib, self._lib.gymrs_get_obs(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get_state(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n_envs - first if count is None else count
+        out = np.empty((self.state_dim, count), dtype=np.float32)
+        _check(self._lib, self._lib.gymrs_get_state(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def set_state(self, state, first: int = 0) -> None:
+        arr = np.ascontiguousarray(state, dtype=np.float32)
+        if arr.ndim != 2 or arr.shape[0] != self.state_dim:
+            raise ValueError(f"state must have shape ({self.state_dim}, count)")
+        _check(self._lib, self._lib.gymrs_set_state(self._h, first, arr.shape[1], arr.ctypes.data_as(C.c_void_p)))
+
+    def get_step_result(self, first: int = 0, count: Optional[int] = None):
+        count = self.n_envs - first if count is None else count
+        reward = np.empty(count, dtype=np.float32)
+        done = np.empty(count, dtype=np.uint8)
+        trunc = np.empty(count, dtype=np.uint8)
+        _check(self._lib, self._lib.gymrs_get_step_result(self._h, first, count, reward.ctypes.data_as(C.c_void_p),
+                                                          done.ctypes.data_as(C.c_void_p), trunc.ctypes.data_as(C.c_void_p)))
+        return reward, done, trunc
+
+    # -- statistics ----------------------------------------------------------------------------------
+    def stats(self) -> np.ndarray:
+        """{sum_return, sum_length, n_episodes, n_steps} of this shard."""
+        out = (C.c_double * 4)()
+        _check(self._lib, self._lib.gymrs_stats(self._h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def stats_clear(self) -> None:
+        _check(self._lib, self._lib.gymrs_stats_clear(self._h))
+
+    def stats_device(self) -> int:
+        """Device address of 4 doubles, valid after the engine stream reaches this point."""
+        p = C.c_void_p()
+        _check(self._lib, self._lib.gymrs_stats_device(self._h, C.byref(p)))
+        return p.value or 0
+
+    # RCCL, one process per GPU
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(self._lib, self._lib.gymrs_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: bytes) -> None:
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(self._lib, self._lib.gymrs_comm_init(self._h, n_ranks, rank, buf))
+
+    def allreduce_stats(self) -> np.ndarray:
+        out = (C.c_double * 4)()
+        _check(self._lib, self._lib.gymrs_allreduce_stats(self._h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    # -- utilities -----------------------------------------------------------------------------------
+    def fill_actions(self, actions_dev: int, seed: int, t: int) -> None:
+        _check(self._lib, self._lib.gymrs_fill_actions(self._h, C.c_void_p(actions_dev), int(seed), int(t)))
+
+    def tick(self) -> Tuple[int, int]:
+        t, s = C.c_uint64(), C.c_uint64()
+        _check(self._lib, self._lib.gymrs_get_tick(self._h, C.byref(t), C.byref(s)))
+        return t.value, s.value

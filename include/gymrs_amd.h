@@ -1,0 +1,198 @@
+/*
+ * gymrs_amd.h — C ABI of the MI355X-native batched classic-control stepper.
+ *
+ * This is the drop-in boundary for the ONE hot path of MathisWellmann/gym-rs:
+ * Env::step() (+ the reset() that re-arms a finished lane) of CartPole / MountainCar
+ * (/ a spec-derived Pendulum).  The reference has no FFI; its boundary is the trait pair in
+ * src/core.rs.  Each entry point below cites the reference interface it replaces, with
+ * paths relative to /root/reference.  The binding a gym-rs maintainer would add (a Rust
+ * `extern "C"` block + `impl Env`) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only.  Device pointers are HIP device addresses.
+ *   - Every function returns a gymrs_status instead of panicking (the reference asserts:
+ *     cartpole.rs:402-406); gymrs_last_error() gives the message for the calling thread.
+ *   - The engine owns its device buffers.  The caller owns every host buffer it passes.
+ *   - gymrs_step* are asynchronous on the engine's HIP stream; gymrs_sync() waits.
+ *   - One engine is driven by one host thread at a time (the reference's methods take
+ *     `&mut self`, core.rs:42-50).  Engines on different GPUs may be driven concurrently.
+ *   - N independent envs ("lanes") live as SoA f32 arrays in HBM; lane i of an engine has the
+ *     global id global_env_offset + i, which (with the seed and the engine tick) fully
+ *     determines its reset draws, so results do not depend on how lanes are sharded over GPUs.
+ */
+#ifndef GYMRS_AMD_H
+#define GYMRS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GYMRS_ABI_VERSION 1
+
+typedef struct gymrs_engine gymrs_engine; /* opaque; owns device buffers + stream */
+
+typedef enum {
+    GYMRS_OK = 0,
+    GYMRS_EINVAL = 1,  /* bad argument */
+    GYMRS_EHIP = 2,    /* HIP runtime error */
+    GYMRS_ENCCL = 3,   /* RCCL error */
+    GYMRS_ENOMEM = 4,  /* allocation failed */
+    GYMRS_EACTION = 5, /* an action outside the action space was seen (reference: assert! panic,
+                          cartpole.rs:402-406, mountain_car.rs:402-406); the offending lanes were
+                          left untouched */
+} gymrs_status;
+
+/* classical_control/mod.rs:1-4 exports cartpole and mountain_car.  Pendulum is NOT in the
+ * reference (spec-derived from Gym's Pendulum-v1). */
+typedef enum { GYMRS_CARTPOLE = 0, GYMRS_MOUNTAIN_CAR = 1, GYMRS_PENDULUM = 2 } gymrs_env_kind;
+
+/* Engine flags.  The reference has none of these behaviours: with flags = 0 a
+ * lane behaves exactly like one reference env (no auto-reset, no truncation). */
+enum {
+    GYMRS_AUTO_RESET = 1u,  /* a lane whose step returned done (or truncated) is re-armed inside
+                               the same kernel: the caller loop of examples/cartpole.rs:23-28 */
+    GYMRS_TRACK_STATS = 2u, /* accumulate {sum_return, sum_length, n_episodes} of finished episodes
+                               (needs GYMRS_AUTO_RESET) */
+    GYMRS_TIME_LIMIT = 4u,  /* truncated = (steps in episode >= max_episode_steps); the cap the
+                               reference leaves to its callers (examples/cartpole.rs:18) */
+};
+
+/* Physics constants: the `pub` fields of the reference env structs, in f64 like the reference
+ * (O64).  They are converted to f32 once at engine creation.  Pass NULL for the defaults. */
+typedef struct {
+    double gravity;                 /* 9.8    cartpole.rs:94  */
+    double masscart;                /* 1.0    cartpole.rs:95  */
+    double masspole;                /* 0.1    cartpole.rs:96  */
+    double length;                  /* 0.5    cartpole.rs:97  */
+    double force_mag;               /* 10.0   cartpole.rs:98  */
+    double tau;                     /* 0.02   cartpole.rs:99  */
+    double theta_threshold_radians; /* 12*2*pi/360  cartpole.rs:102 */
+    double x_threshold;             /* 2.4    cartpole.rs:103 */
+    int32_t kinematics_integrator;  /* 0 Euler (cartpole.rs:100), 1 Other (cartpole.rs:436-441) */
+    uint32_t max_episode_steps;     /* used with GYMRS_TIME_LIMIT; 0 -> 500 (doc cartpole.rs:50) */
+} gymrs_cartpole_params;
+
+typedef struct {
+    double min_position;  /* -1.2   mountain_car.rs:344 */
+    double max_position;  /* 0.6    mountain_car.rs:345 */
+    double max_speed;     /* 0.07   mountain_car.rs:346 */
+    double goal_position; /* 0.5    mountain_car.rs:347 */
+    double goal_velocity; /* 0.0    mountain_car.rs:348 */
+    double force;         /* 0.001  mountain_car.rs:350 */
+    double gravity;       /* 0.0025 mountain_car.rs:351 */
+    uint32_t max_episode_steps; /* 0 -> 200 (doc mountain_car.rs:45) */
+    uint32_t _pad;
+} gymrs_mountain_car_params;
+
+typedef struct { /* spec-derived (Gym Pendulum-v1), not in the reference */
+    double max_speed;  /* 8    */
+    double max_torque; /* 2    */
+    double dt;         /* 0.05 */
+    double g;          /* 10   */
+    double m;          /* 1    */
+    double l;          /* 1    */
+    uint32_t max_episode_steps; /* 0 -> 200 */
+    uint32_t _pad;
+} gymrs_pendulum_params;
+
+/* Fill *params (a gymrs_*_params of the right kind) with the defaults of CartPoleEnv::new /
+ * MountainCarEnv::new (cartpole.rs:91-144, mountain_car.rs:341-390). */
+gymrs_status gymrs_default_params(gymrs_env_kind kind, void* params);
+
+/* ---- spaces: EnvProperties::action_space / observation_space (core.rs:86-89) -------------- */
+/* Discrete(n) for CartPole (2, cartpole.rs:114) and MountainCar (3, mountain_car.rs:362);
+ * *n = 0 for Pendulum, whose action space is the box [-max_torque, max_torque]. */
+gymrs_status gymrs_action_space(gymrs_env_kind kind, uint32_t* n, double* box_low, double* box_high);
+/* BoxR{low, high}: cartpole.rs:105-115, mountain_car.rs:353-364.  low/high hold *dim doubles
+ * (capacity >= 4). */
+gymrs_status gymrs_observation_space(gymrs_env_kind kind, const void* params, double* low, double* high,
+                                     int* dim);
+/* Discrete::contains (spaces/discrete.rs:14-19): value < n. */
+int gymrs_discrete_contains(uint64_t n, uint64_t value);
+
+/* ---- lifetime: CartPoleEnv::new / MountainCarEnv::new -------------------------------------- */
+/* Like ::new (cartpole.rs:92,120), creation seeds from OS entropy and samples an initial state,
+ * so the engine is steppable before the first gymrs_reset(). */
+gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t global_env_offset, int device,
+                                 const void* params /* NULL = defaults */, uint32_t flags, gymrs_engine** out);
+/* Env::close (core.rs:56) + drop. */
+gymrs_status gymrs_engine_destroy(gymrs_engine* e);
+
+/* Use an externally created hipStream_t (e.g. the host framework's) instead of the engine's own. */
+gymrs_status gymrs_set_stream(gymrs_engine* e, void* hip_stream);
+gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream);
+
+/* ---- Env::reset(seed, return_info, options) (core.rs:45-50) -------------------------------- */
+/* has_seed = 0 re-seeds from OS entropy (seeding.rs:22); the same seed always gives the same
+ * states.  bounds_low_high = obs_dim lows then obs_dim highs replacing the default
+ * sampling box (`options`, cartpole.rs:352-364, mountain_car.rs:175-190), or NULL.
+ * *seed_used (may be NULL) receives the seed number, like rand_random's second return value
+ * (seeding.rs:21-26). */
+gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const float* bounds_low_high,
+                         uint64_t* seed_used);
+
+/* ---- Env::step(action) (core.rs:42) --------------------------------------------------------- */
+/* actions_dev: n_envs actions on the device: uint8_t for CartPole {0,1} / MountainCar {0,1,2},
+ * float for Pendulum.  Asynchronous.  Results land in the arrays below. */
+gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev);
+/* Same with a host action buffer (copied first); for the single-env compatibility layer. */
+gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host);
+/* n_steps consecutive step() calls; step t reads its actions at
+ * actions_dev + (t % n_buffers) * stride_bytes.  use_graph != 0 replays a captured HIP graph. */
+gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes,
+                             uint32_t n_buffers, uint32_t n_steps, int use_graph);
+/* Wait for the stream; returns GYMRS_EACTION if any step since the last sync saw an invalid action. */
+gymrs_status gymrs_sync(gymrs_engine* e);
+
+/* ---- ActionReward{observation, reward, done, truncated} (core.rs:94-106), batched ------------ */
+/* Zero-copy SoA device views, valid until destroy.  CartPole obs = (x, x_dot, theta, theta_dot)
+ * (cartpole.rs:336-349), MountainCar obs = (position, velocity) (mountain_car.rs:193-197); for
+ * these the observation IS the state array.  Pendulum obs = (cos, sin, theta_dot). */
+gymrs_status gymrs_obs_ptrs(gymrs_engine* e, float** out_ptrs /* capacity 4 */, int* obs_dim);
+gymrs_status gymrs_state_ptrs(gymrs_engine* e, float** out_ptrs /* capacity 4 */, int* state_dim);
+gymrs_status gymrs_reward_ptr(gymrs_engine* e, float** out);
+gymrs_status gymrs_done_ptr(gymrs_engine* e, uint8_t** out);
+gymrs_status gymrs_truncated_ptr(gymrs_engine* e, uint8_t** out);
+
+/* Host copies (synchronising).  SoA: dim arrays of `count` floats, back to back.
+ * get/set_state is the engine's Clone/Serialize equivalent (core.rs:25). */
+gymrs_status gymrs_get_obs(gymrs_engine* e, uint64_t first, uint64_t count, float* host_out);
+gymrs_status gymrs_get_state(gymrs_engine* e, uint64_t first, uint64_t count, float* host_out);
+gymrs_status gymrs_set_state(gymrs_engine* e, uint64_t first, uint64_t count, const float* host_in);
+gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t count, float* reward,
+                                   uint8_t* done, uint8_t* truncated /* each may be NULL */);
+
+/* ---- episode statistics (the all-reduce payload) --------------------------------------------- */
+/* out = {sum_return, sum_length, n_episodes, n_steps} for this engine's lanes (synchronising). */
+gymrs_status gymrs_stats(gymrs_engine* e, double out[4]);
+gymrs_status gymrs_stats_clear(gymrs_engine* e);
+/* Reduce the per-workgroup partials into 4 doubles in device memory (async on the engine's stream)
+ * and return that device address, e.g. to hand it to an RCCL all-reduce. */
+gymrs_status gymrs_stats_device(gymrs_engine* e, double** dev_out4);
+
+/* RCCL over xGMI: one process per GPU.  Rank 0 makes an id, the host framework distributes the
+ * 128 bytes, every rank joins, then gymrs_allreduce_stats sums the 4 doubles over all ranks. */
+gymrs_status gymrs_comm_unique_id(uint8_t id_out[128]);
+gymrs_status gymrs_comm_init(gymrs_engine* e, int n_ranks, int rank, const uint8_t id[128]);
+gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
+
+/* ---- utilities --------------------------------------------------------------------------------- */
+/* Random-policy actions for lane block [0, n_envs) at time t, written to actions_dev: the
+ * `rng.gen_range(0..=1)` of examples/cartpole.rs:19, generated on the device so no PCIe traffic
+ * sits in a timed loop.  Philox stream 1, key = seed, counter = (global id, t). */
+gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t seed, uint64_t t);
+/* Engine tick (number of reset()/step() calls since the last seeded reset) and current seed. */
+gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
+/* Kernel geometry knobs for tuning/benchmarks: lanes per work-item (1, 2 or 4). */
+gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved);
+
+const char* gymrs_last_error(void);
+int gymrs_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GYMRS_AMD_H */

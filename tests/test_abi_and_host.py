@@ -1,0 +1,141 @@
+"""CPU tests of the drop-in boundary and the host logic: the C-ABI library loads and exports every
+symbol include/gymrs_amd.h declares; spaces and constants match the reference; the product fails
+LOUDLY without a GPU (no CPU fallback); lane sharding + the statistics all-reduce over 2 ranks (gloo)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def header_symbols():
+    text = (ROOT / "include" / "gymrs_amd.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gymrs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol(gymrs):
+    lib = gymrs.load_library()
+    names = header_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/gymrs_amd.h but not exported"
+    from importlib import import_module
+
+    sigs = import_module("gym-rs_amd._lib").SIGNATURES
+    assert sorted(sigs) == names, "ctypes binding table and header disagree"
+    assert lib.gymrs_abi_version() == 1
+
+
+def test_default_params_match_reference_constants(gymrs, golden):
+    cp = gymrs.engine.default_params(gymrs.CARTPOLE)
+    for k, v in golden("cartpole")["constants"].items():  # cartpole.rs:94-103
+        assert getattr(cp, k) == v
+    mc = gymrs.engine.default_params(gymrs.MOUNTAIN_CAR)
+    for k, v in golden("mountain_car")["constants"].items():  # mountain_car.rs:344-351
+        assert getattr(mc, k) == v
+    pd = gymrs.engine.default_params(gymrs.PENDULUM)
+    for k, v in golden("pendulum")["constants"].items():
+        assert getattr(pd, k) == v
+
+
+def test_spaces_match_reference(gymrs):
+    lib = gymrs.load_library()
+    n = C.c_uint32()
+    assert lib.gymrs_action_space(0, C.byref(n), None, None) == 0 and n.value == 2  # cartpole.rs:114
+    assert lib.gymrs_action_space(1, C.byref(n), None, None) == 0 and n.value == 3  # mountain_car.rs:362
+    lo, hi, dim = (C.c_double * 4)(), (C.c_double * 4)(), C.c_int()
+    assert lib.gymrs_observation_space(0, None, lo, hi, C.byref(dim)) == 0 and dim.value == 4
+    # cartpole.rs:105-113: +-(4.8, inf, 0.41887902047863906, inf)
+    assert list(hi) == [4.8, float("inf"), 0.41887902047863906, float("inf")] and list(lo) == [-v for v in hi]
+    assert lib.gymrs_observation_space(1, None, lo, hi, C.byref(dim)) == 0 and dim.value == 2
+    assert list(lo)[:2] == [-1.2, -0.07] and list(hi)[:2] == [0.6, 0.07]  # mountain_car.rs:353-354
+
+
+def test_no_cpu_fallback_without_gpu(gymrs):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(gymrs.GymrsError) as exc:
+        gymrs.BatchedEngine(gymrs.CARTPOLE, 16)
+    assert "no CPU fallback" in str(exc.value) or "HIP" in str(exc.value)
+    with pytest.raises(gymrs.GymrsError):
+        gymrs.CartPoleEnv()
+
+
+def test_bad_arguments_are_status_codes_not_crashes(gymrs):
+    lib = gymrs.load_library()
+    h = C.c_void_p()
+    assert lib.gymrs_engine_create(7, 16, 0, 0, None, 0, C.byref(h)) == 1  # unknown kind -> GYMRS_EINVAL
+    assert b"unknown env kind" in lib.gymrs_last_error()
+    assert lib.gymrs_engine_create(0, 0, 0, 0, None, 0, C.byref(h)) == 1
+    assert lib.gymrs_engine_create(0, 16, 0, 0, None, 2, C.byref(h)) == 1  # TRACK_STATS without AUTO_RESET
+    assert lib.gymrs_step(None, None) == 1 and lib.gymrs_sync(None) == 1
+    assert lib.gymrs_engine_destroy(None) == 0
+
+
+def test_shard_range_covers_batch(gymrs):
+    for n, w in ((1 << 23, 8), (1000, 3), (5, 8)):
+        spans = [gymrs.shard_range(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+        for (o1, c1), (o2, _) in zip(spans, spans[1:]):
+            assert o1 + c1 == o2
+    assert gymrs.shard_range(1 << 23, 8, 3) == (3 << 20, 1 << 20)
+    with pytest.raises(ValueError):
+        gymrs.shard_range(10, 2, 2)
+
+
+WORKER = r"""
+import os, sys, importlib
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+gymrs = importlib.import_module("gym-rs_amd")
+from oracle.bindings import Twin, TwinEngine
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+N, STEPS = 6000, 40
+flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+off, cnt = gymrs.shard_range(N, world, rank)
+tw = Twin()
+P = gymrs.engine.default_params(0)
+shard = TwinEngine(tw, 0, cnt, P, flags=flags, gid0=off)   # the f32 twin stands in for the GPU shard on CPU
+shard.reset(11)
+for t in range(STEPS):
+    shard.step(shard.fill_actions(1, t))
+st = torch.tensor(shard.stats(), dtype=torch.float64)
+dist.all_reduce(st)                                          # the ONLY collective of the path: 4 doubles
+state = shard.get_state()
+gathered = [None] * world
+dist.all_gather_object(gathered, (off, state))
+if rank == 0:
+    full = TwinEngine(tw, 0, N, P, flags=flags, gid0=0)     # the same batch unsharded
+    full.reset(11)
+    for t in range(STEPS):
+        full.step(full.fill_actions(1, t))
+    assert np.array_equal(st.numpy(), full.stats()), (st.numpy(), full.stats())
+    cat = np.concatenate([s for _, s in sorted(gathered, key=lambda x: x[0])], axis=1)
+    assert np.array_equal(cat.view(np.uint32), full.get_state().view(np.uint32)), "sharding changed a lane"
+    print("SHARD_OK", st.tolist())
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_sharding_and_allreduce_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): shard-invariance (global env ids feed the Philox counter) and
+    all-reduce(sum) of per-shard statistics == statistics of the unsharded batch."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", str(script), str(ROOT)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "SHARD_OK" in res.stdout

@@ -1,0 +1,105 @@
+"""The single-env compatibility layer on a real GPU: reads like a test of the reference crate —
+`CartPoleEnv::new(RenderMode::None)`, `env.step(action)`, `env.reset(seed, return_info, options)`,
+`env.action_space()`, `env.observation_space()` (core.rs:25-90) — with one lane of the batched engine
+behind it.  Expected values: tests/golden."""
+import math
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cartpole_env_surface_and_kat(gymrs, golden):
+    env = gymrs.CartPoleEnv(gymrs.RenderMode.NONE)
+    assert env.action_space() == gymrs.Discrete(2)
+    space = env.observation_space()
+    assert space.high.to_vec() == [4.8, math.inf, 0.41887902047863906, math.inf] and space.low == -space.high
+    assert env.gravity == 9.8 and env.masspole == 0.1 and env.length == 0.5 and env.tau == 0.02  # pub fields
+    assert env.reward_range() == gymrs.RewardRange() and env.render_mode() is gymrs.RenderMode.NONE
+    obs, info = env.reset(seed=64, return_info=True)
+    assert info == () and all(abs(v) < 0.05 for v in obs.to_vec())
+    obs2, info2 = env.reset(seed=64)
+    assert info2 is None and obs2 == obs  # same seed, same state
+    for tr in golden("cartpole")["trajectories"]:
+        policy = {"always_1": lambda t: 1, "always_0": lambda t: 0, "alternate_1_0": lambda t: (t + 1) % 2}[tr["policy"]]
+        env.state = gymrs.CartPoleObservation(*tr["start"])
+        t, total = 0, 0.0
+        while True:
+            ar = env.step(policy(t))
+            assert ar.truncated is False and ar.info == ()  # cartpole.rs:480-481
+            total += ar.reward
+            t += 1
+            if ar.done:
+                break
+        assert t == tr["steps"] and total == float(tr["steps"])  # 10 / 9 / 60
+        assert ar.observation.to_vec() == pytest.approx(tr["final"], rel=2e-4)
+    # stepping past termination pays 1.0 once, then 0.0 (cartpole.rs:455-464)
+    bt = golden("cartpole")["beyond_terminated"]
+    env.state = gymrs.CartPoleObservation(*bt["start"])
+    rewards = [env.step(bt["action"]).reward for _ in bt["rewards"]]
+    assert rewards == bt["rewards"]
+    with pytest.raises(AssertionError):  # assert!(self.action_space.contains(action)) cartpole.rs:402-406
+        env.step(2)
+    env.close()
+
+
+def test_cartpole_first_step_matches_known_answer(gymrs):
+    env = gymrs.CartPoleEnv()
+    env.state = gymrs.CartPoleObservation(0.01, 0.02, 0.03, 0.04)
+    ar = env.step(1)
+    # SURVEY Appendix C; 0.356 (reference, polemass_length = 0.6), not Gym's 0.215 (Q1)
+    assert ar.observation.to_vec() == pytest.approx([0.0104, 0.35615076996399875, 0.0308, -0.2430694901285738], rel=1e-6)
+    assert ar.reward == 1.0 and ar.done is False
+    env.close()
+
+
+def test_mountain_car_env_surface_and_kat(gymrs, golden):
+    env = gymrs.MountainCarEnv(gymrs.RenderMode.NONE)
+    assert env.action_space() == gymrs.Discrete(3)
+    space = env.observation_space()
+    assert space.low.to_vec() == [-1.2, -0.07] and space.high.to_vec() == [0.6, 0.07]
+    obs, _ = env.reset(seed=1)
+    assert -0.6 <= obs.position < -0.4 and obs.velocity == 0.0  # mountain_car.rs:162-167
+    tr = golden("mountain_car")["trajectories"][0]
+    env.state = gymrs.MountainCarObservation(*tr["start"])
+    t, total = 0, 0.0
+    while True:
+        ar = env.step(2 if env.state.velocity >= 0 else 0)
+        assert ar.info is None and ar.truncated is False  # mountain_car.rs:432-433
+        total += ar.reward
+        t += 1
+        if ar.done:
+            break
+    assert t == 124 and total == -124.0
+    assert ar.observation.to_vec() == pytest.approx(tr["final"], rel=1e-4)
+    env.state = gymrs.MountainCarObservation(-1.19, -0.07)
+    ar = env.step(0)
+    assert ar.observation.to_vec() == [pytest.approx(-1.2), 0.0] and not ar.done  # wall rule
+    with pytest.raises(AssertionError):
+        env.step(3)
+    env.close()
+
+
+def test_pendulum_env_spec(gymrs, golden):
+    env = gymrs.PendulumEnv()
+    tr = golden("pendulum")["trajectory"]
+    env.state = tr["start"]
+    ret = 0.0
+    for t in range(tr["steps"]):
+        ar = env.step(2.0 if (t // 10) % 2 == 0 else -2.0)
+        ret += ar.reward
+        assert not ar.done
+    assert ret == pytest.approx(tr["total_reward"], rel=1e-4)
+    assert list(env.state) == pytest.approx(tr["final"], rel=1e-3)
+    env.close()
+
+
+def test_mutable_physics_fields(gymrs):
+    env = gymrs.CartPoleEnv()
+    env.state = gymrs.CartPoleObservation(0.0, 0.0, 0.05, 0.0)
+    a = env.step(1).observation
+    env.state = gymrs.CartPoleObservation(0.0, 0.0, 0.05, 0.0)
+    env.force_mag = 20.0  # pub field (cartpole.rs:61)
+    b = env.step(1).observation
+    assert b.x_dot > a.x_dot * 1.5
+    env.close()

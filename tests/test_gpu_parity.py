@@ -1,0 +1,313 @@
+"""GPU parity tests proper: the gfx950 kernels, called through the C ABI (include/gymrs_amd.h), against
+  (1) the f64 C oracle — per single step, |gpu - ref| <= 1e-6 * max(|ref|, 1) (north_star tolerance);
+  (2) the CPU f32 twin — BIT-EXACT state words, rewards, done/truncated flags and integer episode /
+      step counts over multi-step runs with auto-reset;
+  (3) the committed golden vectors (tests/golden);
+  (4) size-independent properties at BASELINE.json's full sizes (2^20 / 2^22 lanes)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.bindings import TwinEngine
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def mixed_err(got, ref):
+    return np.abs(got.astype(np.float64) - ref) / np.maximum(np.abs(ref), 1.0)
+
+
+def dev_actions(n, kind):
+    return torch.empty(n, dtype=torch.float32 if kind == 2 else torch.uint8, device="cuda:0")
+
+
+def random_states(kind, n, rng):
+    if kind == 0:
+        st = np.stack([rng.uniform(-2.4, 2.4, n), rng.uniform(-3, 3, n), rng.uniform(-0.21, 0.21, n), rng.uniform(-3, 3, n)])
+        act = rng.integers(0, 2, n).astype(np.uint8)
+    elif kind == 1:
+        st = np.stack([rng.uniform(-1.2, 0.6, n), rng.uniform(-0.07, 0.07, n)])
+        act = rng.integers(0, 3, n).astype(np.uint8)
+    else:
+        st = np.stack([rng.uniform(-40, 40, n), rng.uniform(-8, 8, n)])
+        act = rng.uniform(-2.5, 2.5, n).astype(np.float32)
+    return st.astype(np.float32), act
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("vec", [1, 2, 4])
+def test_single_step_vs_f64_oracle(kind, vec, gymrs, oracle):
+    n = 100_003  # ragged: not a multiple of any workgroup tile
+    rng = np.random.default_rng(100 + kind)
+    st, act = random_states(kind, n, rng)
+    with gymrs.BatchedEngine(kind, n, flags=0, lanes_per_thread=vec) as eng:
+        eng.reset(seed=1)
+        eng.set_state(st)
+        eng.step_host(act)
+        got = eng.get_state()
+        reward, done, trunc = eng.get_step_result()
+        obs = eng.get_obs()
+    ref = st.astype(np.float64).copy()
+    if kind == 0:
+        ref_r, ref_d, bad = oracle.cartpole_step_batch(ref, np.zeros(n, np.uint8), act)
+        near = (np.abs(np.abs(ref[0]) - 2.4) < 1e-5) | (np.abs(np.abs(ref[2]) - 0.20943951023931953) < 1e-5)
+    elif kind == 1:
+        ref_r, ref_d, bad = oracle.mountain_car_step_batch(ref, act)
+        near = (np.abs(ref[0] - 0.5) < 1e-5) | (np.abs(ref[1]) < 1e-5)
+    else:
+        ref_r, oc, os_ = oracle.pendulum_step_batch(ref, act.astype(np.float64))
+        ref_d, bad, near = np.zeros(n, np.uint8), 0, np.zeros(n, bool)
+        scale = np.maximum(np.abs(ref[0]), 1.0)  # cos/sin inherit the f32 representation error of theta
+        assert (np.abs(obs[0] - oc) / scale).max() <= TOL and (np.abs(obs[1] - os_) / scale).max() <= TOL
+        assert np.array_equal(obs[2], got[1])
+    assert bad == 0
+    assert mixed_err(got, ref).max() <= TOL
+    assert mixed_err(reward, ref_r).max() <= TOL
+    assert not trunc.any()  # truncated is hard-coded false in the reference (cartpole.rs:480)
+    mism = np.nonzero(done != ref_d)[0]
+    assert near[mism].all(), f"{len(mism)} done mismatches outside the 1e-5 threshold band"
+    if kind != 2:
+        assert np.array_equal(obs, got)  # the observation IS the state (cartpole.rs:476-482)
+
+
+FLAG_SETS = ["0", "A", "A|S", "T", "A|T", "A|S|T"]
+
+
+def parse_flags(gymrs, s):
+    m = {"0": 0, "A": gymrs.AUTO_RESET, "S": gymrs.TRACK_STATS, "T": gymrs.TIME_LIMIT}
+    f = 0
+    for part in s.split("|"):
+        f |= m[part]
+    return f
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("flagset", FLAG_SETS)
+def test_multistep_bit_exact_vs_f32_twin(kind, flagset, gymrs, twin):
+    """Everything the kernel adds around the physics (vector tails, ballot/LDS compaction, Philox
+    counters, statistics partials, time limit) must not change a single bit."""
+    flags = parse_flags(gymrs, flagset)
+    n, steps = 20_011, 60
+    params = gymrs.engine.default_params(kind)
+    if flags & gymrs.TIME_LIMIT:
+        params.max_episode_steps = 17
+    for vec in (4, 1):
+        eng = gymrs.BatchedEngine(kind, n, flags=flags, params=params, global_env_offset=12345, lanes_per_thread=vec)
+        tw = TwinEngine(twin, kind, n, params, flags=flags, gid0=12345)
+        eng.reset(seed=2024)
+        tw.reset(2024)
+        assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+        acts = dev_actions(n, kind)
+        for t in range(steps):
+            eng.fill_actions(acts.data_ptr(), seed=9, t=t)
+            eng.step(acts.data_ptr())
+            a_host = tw.fill_actions(9, t)
+            if t == 0:
+                eng.sync()
+                assert np.array_equal(acts.cpu().numpy(), a_host)  # the action stream itself
+            tw.step(a_host)
+            if t % 20 == 19 or t == steps - 1:
+                eng.sync()
+                assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32)), (vec, t)
+                gr, gd, gt = eng.get_step_result()
+                tr, td, tt = tw.get_result()
+                assert np.array_equal(gr.view(np.uint32), tr.view(np.uint32))
+                assert np.array_equal(gd, td) and np.array_equal(gt, tt)
+                assert np.array_equal(eng.get_obs().view(np.uint32), tw.get_obs().view(np.uint32))
+        gs, ts = eng.stats(), tw.stats()
+        assert gs[1] == ts[1] and gs[2] == ts[2] and gs[3] == ts[3] == n * steps  # integer counts: exact
+        if kind == 2:
+            assert gs[0] == pytest.approx(ts[0], rel=1e-5)  # float sum, order differs
+        else:
+            assert gs[0] == ts[0]
+        if flags & gymrs.TRACK_STATS and kind == 0:
+            assert gs[2] > 0  # episodes did finish
+        eng.close()
+
+
+def test_step_many_equals_repeated_step(gymrs, twin):
+    n, steps, nbuf = 5000, 33, 4
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    eng = gymrs.BatchedEngine(0, n, flags=flags)
+    tw = TwinEngine(twin, 0, n, eng.params, flags=flags)
+    eng.reset(seed=5)
+    tw.reset(5)
+    bufs = torch.empty((nbuf, n), dtype=torch.uint8, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(bufs[b].data_ptr(), seed=3, t=b)
+    eng.step_many(bufs.data_ptr(), n, nbuf, steps)
+    eng.sync()
+    for t in range(steps):
+        tw.step(tw.fill_actions(3, t % nbuf))
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    assert np.array_equal(eng.stats(), tw.stats())
+    assert eng.tick()[0] == steps + 1
+    eng.close()
+
+
+def test_golden_vectors_on_gpu(gymrs, golden):
+    cp = golden("cartpole")
+    cases = cp["single_steps"]
+    st = np.array([c["state"] for c in cases], np.float64).T
+    act = np.array([c["action"] for c in cases], np.uint8)
+    with gymrs.BatchedEngine(0, len(cases)) as eng:
+        eng.set_state(st.astype(np.float32))
+        eng.step_host(act)
+        got = eng.get_state()
+        _, done, _ = eng.get_step_result()
+    want = np.array([c["next"] for c in cases]).T
+    # inputs differ by f32 rounding (<= 6e-8 relative), amplified by at most ~|d next/d state| ~ 20
+    assert mixed_err(got, want).max() <= 5e-6
+    far = np.array([abs(abs(c["next"][0]) - 2.4) > 1e-4 and abs(abs(c["next"][2]) - 0.2094395) > 1e-4 for c in cases])
+    assert np.array_equal(done[far].astype(bool), np.array([c["done"] for c in cases])[far])
+    mc = golden("mountain_car")
+    cases = mc["single_steps"]
+    st = np.array([c["state"] for c in cases], np.float64).T
+    act = np.array([c["action"] for c in cases], np.uint8)
+    with gymrs.BatchedEngine(1, len(cases)) as eng:
+        eng.set_state(st.astype(np.float32))
+        eng.step_host(act)
+        got = eng.get_state()
+        reward, _, _ = eng.get_step_result()
+    assert mixed_err(got, np.array([c["next"] for c in cases]).T).max() <= 2e-6
+    assert (reward == -1.0).all()
+
+
+def test_invalid_action_is_reported_and_lane_untouched(gymrs):
+    n = 3000
+    with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET) as eng:
+        eng.reset(seed=1)
+        before = eng.get_state()
+        act = np.zeros(n, np.uint8)
+        act[[7, 1500, 2999]] = [2, 255, 9]  # outside Discrete(2)
+        with pytest.raises(gymrs.InvalidActionError) as exc:  # the reference panics (cartpole.rs:402-406)
+            eng.step_host(act)
+        assert "3 invalid" in str(exc.value) and "lane 7" in str(exc.value)
+        after = eng.get_state()
+        reward, done, _ = eng.get_step_result()
+        bad = np.zeros(n, bool)
+        bad[[7, 1500, 2999]] = True
+        assert np.array_equal(after[:, bad], before[:, bad]) and (reward[bad] == 0).all() and (done[bad] == 0).all()
+        assert not np.array_equal(after[:, ~bad], before[:, ~bad])
+        eng.step_host(np.ones(n, np.uint8))  # the error flag was cleared; valid steps work again
+
+
+def test_reset_semantics(gymrs, oracle):
+    n = 4096
+    with gymrs.BatchedEngine(0, n, global_env_offset=1 << 20) as eng:
+        a = eng.get_state()
+        assert np.abs(a).max() < 0.05 and a.std() > 0.02  # ::new samples an initial state (cartpole.rs:120)
+        used = eng.reset(seed=42)
+        assert used == 42  # seed echo (seeding.rs:33-39)
+        s1 = eng.get_state()
+        eng.step_host(np.ones(n, np.uint8))
+        eng.reset(seed=42)
+        assert np.array_equal(s1, eng.get_state())  # same seed, same states
+        ref = oracle.reset_batch(0, n, 1 << 20, 42, 0)
+        assert mixed_err(s1, ref).max() <= TOL
+        u1 = eng.reset()
+        u2 = eng.reset()
+        assert u1 != u2  # OS entropy when seed is None (seeding.rs:22)
+        # options override the sampling box (cartpole.rs:352-364)
+        eng.reset(seed=1, options=[-1, 0, 0.1, 5, 1, 0.5, 0.2, 6])
+        s = eng.get_state()
+        assert s[0].min() >= -1 and s[0].max() < 1 and s[2].min() >= np.float32(0.1) and s[3].min() >= 5 and s[3].max() < 6
+        with pytest.raises(gymrs.GymrsError):
+            eng.reset(seed=1, options=[0, 0, 0, 0, 0, 1, 1, 1])  # low >= high panics in rand
+    with gymrs.BatchedEngine(1, n) as eng:
+        eng.reset(seed=3)
+        s = eng.get_state()
+        assert s[0].min() >= np.float32(-0.6) and s[0].max() < np.float32(-0.4) and (s[1] == 0).all()  # mountain_car.rs:162-167
+
+
+def test_shard_invariance_on_gpu(gymrs):
+    """N lanes on one engine == the concatenation of two shards with global offsets."""
+    n, steps = 8192, 40
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    full = gymrs.BatchedEngine(0, n, flags=flags)
+    full.reset(seed=77)
+    halves = []
+    for r in range(2):
+        off, cnt = gymrs.shard_range(n, 2, r)
+        e = gymrs.BatchedEngine(0, cnt, global_env_offset=off, flags=flags)
+        e.reset(seed=77)
+        halves.append(e)
+    fa = dev_actions(n, 0)
+    for t in range(steps):
+        full.fill_actions(fa.data_ptr(), seed=4, t=t)
+        full.step(fa.data_ptr())
+        for r, e in enumerate(halves):
+            off, cnt = gymrs.shard_range(n, 2, r)
+            ha = dev_actions(cnt, 0)
+            e.fill_actions(ha.data_ptr(), seed=4, t=t)
+            e.step(ha.data_ptr())
+            e.sync()
+    full.sync()
+    cat = np.concatenate([e.get_state() for e in halves], axis=1)
+    assert np.array_equal(cat.view(np.uint32), full.get_state().view(np.uint32))
+    assert np.array_equal(sum(e.stats() for e in halves), full.stats())
+    for e in halves + [full]:
+        e.close()
+
+
+def test_native_rccl_allreduce_single_rank(gymrs):
+    """The C ABI's RCCL path with a 1-rank communicator (the multi-rank case needs >1 GPU)."""
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    with gymrs.BatchedEngine(0, 4096, flags=flags) as eng:
+        eng.reset(seed=1)
+        a = dev_actions(4096, 0)
+        for t in range(30):
+            eng.fill_actions(a.data_ptr(), seed=2, t=t)
+            eng.step(a.data_ptr())
+        local = eng.stats()
+        eng.comm_init(1, 0, eng.comm_unique_id())
+        assert np.array_equal(eng.allreduce_stats(), local)
+
+
+@pytest.mark.parametrize("kind,log2n", [(0, 20), (1, 20), (2, 22)])
+def test_full_size_properties(kind, log2n, gymrs, twin):
+    """BASELINE.json configs 2-4 at full size: properties that hold at any size.
+    - the first 4096 and last 4096 lanes match the f32 twin bit for bit (lanes are independent);
+    - every auto-reset lane sits inside the reset box, every other lane inside the live region;
+    - rewards are the env's constant; episode accounting is conserved:
+      CartPole return == length, MountainCar return == -length, Pendulum episodes == n * steps/limit."""
+    n, steps = 1 << log2n, 25
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if kind == 2 else 0)
+    params = gymrs.engine.default_params(kind)
+    if kind == 2:
+        params.max_episode_steps = 10
+    eng = gymrs.BatchedEngine(kind, n, flags=flags, params=params)
+    eng.reset(seed=123)
+    head = TwinEngine(twin, kind, 4096, params, flags=flags, gid0=0)
+    tail = TwinEngine(twin, kind, 4096, params, flags=flags, gid0=n - 4096)
+    head.reset(123)
+    tail.reset(123)
+    acts = dev_actions(n, kind)
+    for t in range(steps):
+        eng.fill_actions(acts.data_ptr(), seed=6, t=t)
+        eng.step(acts.data_ptr())
+        head.step(head.fill_actions(6, t))
+        tail.step(tail.fill_actions(6, t))
+    eng.sync()
+    assert np.array_equal(eng.get_state(0, 4096).view(np.uint32), head.get_state().view(np.uint32))
+    assert np.array_equal(eng.get_state(n - 4096, 4096).view(np.uint32), tail.get_state().view(np.uint32))
+    st = eng.get_state()
+    reward, done, trunc = eng.get_step_result()
+    stats = eng.stats()
+    assert stats[3] == float(n) * steps
+    if kind == 0:
+        assert (reward == 1.0).all()
+        fresh = done == 1
+        assert (np.abs(st[:, fresh]) < 0.05).all()
+        assert (np.abs(st[0, ~fresh]) <= 2.4).all() and (np.abs(st[2, ~fresh]) <= np.float32(0.20943951023931953)).all()
+        assert stats[0] == stats[1] and 0.02 < done.mean() < 0.12  # ~1/22 of the lanes finish per step
+    elif kind == 1:
+        assert (reward == -1.0).all() and stats[0] == -stats[1]
+        assert (st[0] >= -1.2).all() and (st[0] <= 0.6).all() and (np.abs(st[1]) <= np.float32(0.07)).all()
+    else:
+        assert not done.any()
+        assert stats[2] == float(n) * (steps // 10) and stats[1] == float(n) * 10 * (steps // 10)
+        assert (np.abs(st[1]) <= 8.0).all()
+        assert trunc.sum() == 0  # step 25 is not a multiple of 10
+    eng.close()
