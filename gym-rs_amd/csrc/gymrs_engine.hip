@@ -80,6 +80,9 @@ struct gymrs_engine {
     uint32_t n_stat_blocks = 0;
     uint32_t* err = nullptr;
     double* stats_dev = nullptr;
+    unsigned long long* stats_acc = nullptr;  // [3] scratch of the statistics read-out
+    unsigned long long* stats_base = nullptr; // [1] length sum at the last gymrs_stats_clear
+    uint32_t epoch = 1;                       // ep_start value written by the last reset()
     void* action_staging = nullptr; // for gymrs_step_host
     uint64_t seed = 0, tick = 0;
     double n_steps_total = 0;
@@ -131,6 +134,23 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
         a.lo[j] = e->lo[j];
         a.hi[j] = e->hi[j];
     }
+    return a;
+}
+
+static StatsArgs stats_args(const gymrs_engine* e)
+{
+    StatsArgs a;
+    a.ep_start = e->ep_start;
+    a.n = e->n;
+    a.epoch = e->epoch;
+    a.block_stats = e->block_stats;
+    a.n_blocks = e->n_stat_blocks;
+    a.acc = e->stats_acc;
+    a.base = e->stats_base;
+    a.track = (e->flags & GYMRS_TRACK_STATS) != 0;
+    a.reward_sign = e->kind == GYMRS_CARTPOLE ? 1 : (e->kind == GYMRS_MOUNTAIN_CAR ? -1 : 0);
+    a.n_steps = e->n_steps_total;
+    a.out4 = e->stats_dev;
     return a;
 }
 
@@ -281,6 +301,8 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipFree(e->block_stats);
     (void)hipFree(e->err);
     (void)hipFree(e->stats_dev);
+    (void)hipFree(e->stats_acc);
+    (void)hipFree(e->stats_base);
     (void)hipFree(e->action_staging);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -376,9 +398,11 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->beyond, npad));
     chk(dev_alloc(&e->ep_start, npad));
     e->n_stat_blocks = step_grid(n_envs, 1);
-    chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 4));
+    chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
+    chk(dev_alloc(&e->stats_acc, 3));
+    chk(dev_alloc(&e->stats_base, 1));
     if (st != GYMRS_OK) {
         std::string msg = g_last_error;
         gymrs_engine_destroy(e);
@@ -392,7 +416,6 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     e->own_stream = true;
     static const uint32_t err_init[2] = {0u, 0xffffffffu};
     hipError_t merr = hipMemcpyAsync(e->err, err_init, sizeof(err_init), hipMemcpyHostToDevice, e->stream);
-    if (merr == hipSuccess) merr = hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 4 * sizeof(unsigned long long), e->stream);
     if (merr == hipSuccess) merr = hipMemsetAsync(e->truncated, 0, npad, e->stream);
     if (merr == hipSuccess) merr = hipMemsetAsync(e->stats_dev, 0, 4 * sizeof(double), e->stream);
     if (merr != hipSuccess) {
@@ -486,6 +509,11 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     }
     HIP_TRY(launch_reset(e->kind, a, e->stream));
     e->tick += 1;
+    e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
+    // a reset discards the open episodes and starts the statistics afresh
+    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
+    e->n_steps_total = 0;
     return GYMRS_OK;
 }
 
@@ -627,9 +655,8 @@ gymrs_status gymrs_set_state(gymrs_engine* e, uint64_t first, uint64_t count, co
     HIP_TRY(hipSetDevice(e->device));
     for (int j = 0; j < e->state_dim; ++j)
         HIP_TRY(hipMemcpyAsync(e->s[j] + first, host_in + (size_t)j * count, count * sizeof(float), hipMemcpyHostToDevice, e->stream));
-    // assigning `env.state` in the reference leaves steps_beyond_terminated alone; a fresh state
-    // here starts a fresh episode, which is what every caller of a batched set_state wants.
-    HIP_TRY(launch_clear_beyond_range(e->beyond, e->ep_start, first, count, (uint32_t)e->tick, e->stream));
+    // like assigning the pub `state` field in the reference, this touches nothing else: the episode
+    // (steps_beyond_terminated, elapsed steps) carries on; call gymrs_reset for a fresh one.
     if (e->kind == GYMRS_PENDULUM) {
         // keep the observation columns consistent with the new state
         std::vector<float> c(count), s(count);
@@ -660,7 +687,7 @@ gymrs_status gymrs_stats_device(gymrs_engine* e, double** dev_out4)
 {
     if (!e || !dev_out4) return fail(GYMRS_EINVAL, "gymrs_stats_device: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(launch_stats_reduce(e->block_stats, e->n_stat_blocks, e->n_steps_total, e->stats_dev, e->stream));
+    HIP_TRY(launch_stats(stats_args(e), 0, e->stream));
     *dev_out4 = e->stats_dev;
     return GYMRS_OK;
 }
@@ -679,7 +706,8 @@ gymrs_status gymrs_stats_clear(gymrs_engine* e)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_stats_clear: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 4 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(launch_stats(stats_args(e), 1, e->stream));
     e->n_steps_total = 0;
     return GYMRS_OK;
 }

@@ -21,7 +21,7 @@ struct StepArgs {
     uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
     uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
     float* ep_ret;      // Pendulum with GYMRS_TRACK_STATS: running episode return
-    unsigned long long* block_stats; // [n_blocks][4]: n_episodes, sum_length, sum_return (f64 bits), unused
+    unsigned long long* block_stats; // [n_blocks][2]: finished episodes, sum of returns (f64 bits; Pendulum only)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1
     uint64_t n;         // lanes in this engine
     uint64_t gid0;      // global id of lane 0
@@ -52,10 +52,20 @@ hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepA
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);
-// out4 = {sum_return, sum_length, n_episodes, n_steps}
-hipError_t launch_stats_reduce(const unsigned long long* block_stats, uint32_t n_blocks, double n_steps, double* out4,
-                               hipStream_t stream);
-hipError_t launch_clear_beyond_range(uint8_t* beyond, uint32_t* ep_start, uint64_t first, uint64_t count, uint32_t tick,
-                                     hipStream_t stream);
+struct StatsArgs {
+    const uint32_t* ep_start;
+    uint64_t n;
+    uint32_t epoch;    // value reset() wrote into ep_start
+    const unsigned long long* block_stats;
+    uint32_t n_blocks;
+    unsigned long long* acc;  // [3] scratch: L, E, R
+    unsigned long long* base; // [1] L at the last stats_clear
+    int track;                // GYMRS_TRACK_STATS set
+    int reward_sign;          // +1 CartPole, -1 MountainCar (return = +-length), 0 Pendulum (summed)
+    double n_steps;
+    double* out4;             // {sum_return, sum_length, n_episodes, n_steps}
+};
+// mode 0 read, 1 clear (base = L), 2 after reset (base = 0)
+hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
 
 } // namespace gymrs

@@ -13,10 +13,14 @@
 //     the same lanes come back to the same XCD's L2 every step (blocks are dealt round-robin to
 //     XCDs): the state a step wrote is what the next step reads from L2, not from HBM.
 //   * auto-reset: per wave a __ballot done-mask; quiet waves skip everything.  Finished lanes are
-//     compacted through LDS (ballot + mbcnt ranks, one LDS atomic per wave) so that ONE Philox4x32-10
+//     compacted through the wave's own LDS slice (ballot + mbcnt ranks) so that ONE Philox4x32-10
 //     evaluation is spent per finished lane instead of one per wave-lane under divergence; the fresh
 //     states come back through LDS to the owning work-item, which stores them with its vector store.
-//   * episode statistics: per-workgroup partials in HBM (no same-address atomics on the hot path).
+//     Everything stays inside one wavefront: no s_barrier on the path.
+//   * episode statistics cost the step nothing it can wait on: a finished lane only WRITES the tick
+//     its next episode starts at (episodes tile a lane's time axis, so the sum of finished lengths is
+//     sum(ep_start) - n*epoch, evaluated when statistics are read), plus one fire-and-forget atomic
+//     per wave on a per-workgroup counter.
 #include "gymrs_kernels.h"
 
 namespace gymrs {
@@ -116,50 +120,37 @@ struct PendulumT { // spec-derived, not in the reference
 };
 
 // ---------------------------------------------------------------------------------------------
-// THE hot kernel: one Env::step() per lane, VEC lanes per work-item.
-template <class Env, int VEC, uint32_t FLAGS>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a, const typename Env::Consts c)
+// THE hot kernel: one Env::step() per lane, VEC lanes per work-item, 64*VEC lanes per wavefront.
+//
+// There is no workgroup barrier anywhere: a wavefront owns its lanes from load to store, so the
+// 4 waves of a workgroup (and the workgroups of a CU) drift apart and one wave's arithmetic hides
+// under another wave's memory traffic.
+template <class Env, int VEC, uint32_t FLAGS, bool FULL>
+__device__ __forceinline__ void step_tile(const StepArgs& a, const typename Env::Consts& c, uint16_t* s_list, float* s_new)
 {
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
     constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
     constexpr int NS = Env::kState;
     constexpr int LPB = kBlock * VEC; // lanes per workgroup
+    constexpr int LPW = 64 * VEC;     // lanes per wavefront
     using Action = typename Env::Action;
 
-    __shared__ uint32_t s_cnt;                  // finished lanes in this workgroup
-    __shared__ uint32_t s_sum_len;              // sum of their episode lengths
-    __shared__ float s_sum_ret;                 // sum of their returns (Pendulum only)
-    __shared__ uint16_t s_list[AUTO ? LPB : 1]; // compacted list of finished lanes (workgroup-local index)
-    __shared__ float s_new[AUTO ? NS : 1][AUTO ? LPB : 1]; // their fresh states, by compact slot
-
     const uint32_t tid = threadIdx.x;
-    const uint64_t block_base = (uint64_t)blockIdx.x * LPB;
-    const uint64_t base = block_base + (uint64_t)tid * VEC;
-    const bool full = base + VEC <= a.n;
+    const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)tid * VEC;
     const uint32_t tick_next = (uint32_t)(a.tick + 1);
-
-    if (AUTO) {
-        if (tid == 0) {
-            s_cnt = 0;
-            s_sum_len = 0;
-            s_sum_ret = 0.0f;
-        }
-    }
 
     // ---- loads (issued together; the first use waits) ----
     Vec<float, VEC> st[NS];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) st[j] = load_vec<float, VEC>(a.s[j], base, a.n, full, 0.0f);
-    const Vec<Action, VEC> act = load_vec<Action, VEC>(static_cast<const Action*>(a.action), base, a.n, full, Action(0));
+    for (int j = 0; j < NS; ++j) st[j] = load_vec<float, VEC>(a.s[j], base, a.n, FULL, 0.0f);
+    const Vec<Action, VEC> act = load_vec<Action, VEC>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
     Vec<uint8_t, VEC> beyond;
-    if (Env::kHasBeyond && !AUTO) beyond = load_vec<uint8_t, VEC>(a.beyond, base, a.n, full, uint8_t(0));
+    if (Env::kHasBeyond && !AUTO) beyond = load_vec<uint8_t, VEC>(a.beyond, base, a.n, FULL, uint8_t(0));
     Vec<uint32_t, VEC> ep_start;
-    if (TLIM) ep_start = load_vec<uint32_t, VEC>(a.ep_start, base, a.n, full, 0u);
+    if (TLIM) ep_start = load_vec<uint32_t, VEC>(a.ep_start, base, a.n, FULL, 0u);
     Vec<float, VEC> ep_ret;
-    if (STATS && !Env::kConstReward) ep_ret = load_vec<float, VEC>(a.ep_ret, base, a.n, full, 0.0f);
-
-    if (AUTO) __syncthreads(); // s_cnt = 0 visible; sits under the load latency
+    if (STATS && !Env::kConstReward) ep_ret = load_vec<float, VEC>(a.ep_ret, base, a.n, FULL, 0.0f);
 
     // ---- physics ----
     Vec<float, VEC> reward;
@@ -167,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a, const ty
     bool need_reset[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k) {
-        const bool live = base + k < a.n;
+        const bool live = FULL || (base + k < a.n);
         const Action ak = act.v[k];
         const bool ok = Env::valid(ak);
         float lane_st[NS];
@@ -196,82 +187,97 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a, const ty
         need_reset[k] = AUTO && (d || t);
     }
 
-    // ---- auto-reset: wave ballot -> LDS compaction -> one Philox per finished lane ----
+    // ---- auto-reset: wave __ballot done-mask -> LDS-staged Philox, all inside one wavefront ----
     if (AUTO) {
+        const uint32_t wave = tid >> 6, lane = tid & 63u;
+        uint16_t* list = s_list + wave * LPW;  // this wave's compacted list of finished lanes
+        float* fresh = s_new + wave * NS * LPW; // their new states, [NS][LPW] by compact slot
         uint32_t slot[VEC];
+        uint32_t total = 0; // wave-uniform
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
             slot[k] = 0;
             const unsigned long long m = __ballot(need_reset[k]);
-            if (m != 0ull) { // wave-uniform: quiet waves skip
+            if (m != 0ull) { // wave-uniform
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                uint32_t wave_base = 0;
-                if (need_reset[k] && rank == 0) wave_base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-                wave_base = (uint32_t)__builtin_amdgcn_readlane((int)wave_base, __ffsll((long long)m) - 1);
                 if (need_reset[k]) {
-                    slot[k] = wave_base + rank;
-                    s_list[slot[k]] = (uint16_t)(tid * VEC + k);
+                    slot[k] = total + rank;
+                    list[slot[k]] = (uint16_t)(lane * VEC + k);
                 }
+                total += (uint32_t)__popcll(m);
             }
         }
-        __syncthreads();
-        const uint32_t cnt = s_cnt;
-        if (cnt != 0) { // workgroup-uniform
-            for (uint32_t i = tid; i < cnt; i += kBlock) {
-                const uint32_t local = s_list[i];
-                const uint64_t lane = block_base + local;
-                const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
+        if (total != 0) { // quiet waves skip everything below
+            // DS operations of one wavefront execute in order: no barrier, only keep the compiler
+            // from moving LDS accesses across the hand-over points.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t wave_base = (uint64_t)blockIdx.x * LPB + (uint64_t)wave * LPW;
+            for (uint32_t i = lane; i < total; i += 64u) { // one Philox4x32-10 per finished lane
+                const uint64_t gl = wave_base + list[i];
+                const u32x4 r = draw4(a.seed, a.gid0 + gl, a.tick, kStreamReset);
                 float ns[NS];
                 Env::sample(r, a.lo, a.hi, ns);
 #pragma unroll
-                for (int j = 0; j < NS; ++j) s_new[j][i] = ns[j];
-                if (STATS || TLIM) {
-                    const uint32_t len = tick_next - a.ep_start[lane];
-                    a.ep_start[lane] = tick_next;
-                    if (STATS) atomicAdd(&s_sum_len, len);
-                }
+                for (int j = 0; j < NS; ++j) fresh[j * LPW + i] = ns[j];
+                if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick
             }
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float ret_sum = 0.0f;
 #pragma unroll
             for (int k = 0; k < VEC; ++k) {
                 if (need_reset[k]) {
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) st[j].v[k] = s_new[j][slot[k]];
+                    for (int j = 0; j < NS; ++j) st[j].v[k] = fresh[j * LPW + slot[k]];
                     if (STATS && !Env::kConstReward) {
-                        atomicAdd(&s_sum_ret, ep_ret.v[k]);
+                        ret_sum += ep_ret.v[k];
                         ep_ret.v[k] = 0.0f;
                     }
                 }
             }
             if (STATS) {
-                if (!Env::kConstReward) __syncthreads();
-                if (tid == 0) {
-                    unsigned long long* bs = a.block_stats + (size_t)blockIdx.x * 4;
-                    const uint32_t sum_len = s_sum_len;
-                    bs[0] += cnt;
-                    bs[1] += sum_len;
-                    double* ret = reinterpret_cast<double*>(bs + 2);
-                    *ret += Env::kConstReward ? (double)Env::kRewardValue * (double)sum_len : (double)s_sum_ret;
+                // per-workgroup partials, fire-and-forget (no returned value, no same-address contention)
+                unsigned long long* bs = a.block_stats + (size_t)blockIdx.x * 2;
+                if (!Env::kConstReward) {
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) ret_sum += __shfl_xor(ret_sum, off);
+                    if (lane == 0) atomicAdd(reinterpret_cast<double*>(bs + 1), (double)ret_sum);
                 }
+                if (lane == 0) atomicAdd(bs, (unsigned long long)total);
             }
         }
     }
 
     // ---- stores ----
 #pragma unroll
-    for (int j = 0; j < NS; ++j) store_vec<float, VEC>(a.s[j], base, a.n, full, st[j]);
-    store_vec<float, VEC>(a.reward, base, a.n, full, reward);
-    store_vec<uint8_t, VEC>(a.done, base, a.n, full, done);
-    if (TLIM) store_vec<uint8_t, VEC>(a.truncated, base, a.n, full, trunc);
-    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, VEC>(a.beyond, base, a.n, full, beyond);
-    if (STATS && !Env::kConstReward) store_vec<float, VEC>(a.ep_ret, base, a.n, full, ep_ret);
+    for (int j = 0; j < NS; ++j) store_vec<float, VEC>(a.s[j], base, a.n, FULL, st[j]);
+    store_vec<float, VEC>(a.reward, base, a.n, FULL, reward);
+    store_vec<uint8_t, VEC>(a.done, base, a.n, FULL, done);
+    if (TLIM) store_vec<uint8_t, VEC>(a.truncated, base, a.n, FULL, trunc);
+    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, VEC>(a.beyond, base, a.n, FULL, beyond);
+    if (STATS && !Env::kConstReward) store_vec<float, VEC>(a.ep_ret, base, a.n, FULL, ep_ret);
     if (Env::kHasObsExtra) {
         Vec<float, VEC> oc, os;
 #pragma unroll
         for (int k = 0; k < VEC; ++k) sincosf_(st[0].v[k], &os.v[k], &oc.v[k]);
-        store_vec<float, VEC>(a.obs_cos, base, a.n, full, oc);
-        store_vec<float, VEC>(a.obs_sin, base, a.n, full, os);
+        store_vec<float, VEC>(a.obs_cos, base, a.n, FULL, oc);
+        store_vec<float, VEC>(a.obs_sin, base, a.n, FULL, os);
     }
+}
+
+template <class Env, int VEC, uint32_t FLAGS>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs a, const typename Env::Consts c)
+{
+    constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
+    constexpr int LPB = kBlock * VEC;
+    __shared__ uint16_t s_list[AUTO ? LPB : 1];
+    __shared__ float s_new[AUTO ? Env::kState * LPB : 1];
+    // workgroup-uniform: every workgroup but the last runs the unguarded body
+    if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
+        step_tile<Env, VEC, FLAGS, true>(a, c, s_list, s_new);
+    else
+        step_tile<Env, VEC, FLAGS, false>(a, c, s_list, s_new);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
     a.done[lane] = 0;
     a.truncated[lane] = 0;
     if (Env::kHasBeyond) a.beyond[lane] = 0; // steps_beyond_terminated = None, cartpole.rs:504
-    a.ep_start[lane] = (uint32_t)(a.tick + 1);
+    a.ep_start[lane] = (uint32_t)(a.tick + 1); // = the epoch the statistics are measured from
     if (a.ep_ret) a.ep_ret[lane] = 0.0f;
 }
 
@@ -316,47 +322,62 @@ __global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Acti
     }
 }
 
-// Sum the per-workgroup partials.  One workgroup; n_blocks is at most a few thousand.
-__global__ __launch_bounds__(kBlock) void stats_reduce_kernel(const unsigned long long* __restrict__ bs, uint32_t n_blocks,
-                                                              double n_steps, double* __restrict__ out4)
+// Statistics read-out (off the hot path).  acc = {L, E, R}: L = sum over lanes of
+// (ep_start - epoch) = total length of the episodes finished since the last reset() (episodes tile a
+// lane's time axis), E = finished episodes, R = sum of returns (Pendulum only; for the const-reward
+// envs return = +-length).
+__global__ __launch_bounds__(kBlock) void stats_accumulate_kernel(const uint32_t* __restrict__ ep_start, uint64_t n,
+                                                                  uint32_t epoch,
+                                                                  const unsigned long long* __restrict__ bs,
+                                                                  uint32_t n_blocks, unsigned long long* __restrict__ acc)
 {
-    __shared__ unsigned long long s_ep[kBlock], s_len[kBlock];
+    __shared__ unsigned long long s_len[kBlock], s_ep[kBlock];
     __shared__ double s_ret[kBlock];
-    unsigned long long ep = 0, len = 0;
+    unsigned long long len = 0, ep = 0;
     double ret = 0.0;
-    for (uint32_t b = threadIdx.x; b < n_blocks; b += kBlock) {
-        ep += bs[(size_t)b * 4 + 0];
-        len += bs[(size_t)b * 4 + 1];
-        ret += reinterpret_cast<const double*>(bs)[(size_t)b * 4 + 2];
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) len += (uint32_t)(ep_start[i] - epoch);
+    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_blocks; b += stride) {
+        ep += bs[b * 2];
+        ret += reinterpret_cast<const double*>(bs)[b * 2 + 1];
     }
-    s_ep[threadIdx.x] = ep;
     s_len[threadIdx.x] = len;
+    s_ep[threadIdx.x] = ep;
     s_ret[threadIdx.x] = ret;
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) {
-            s_ep[threadIdx.x] += s_ep[threadIdx.x + off];
             s_len[threadIdx.x] += s_len[threadIdx.x + off];
+            s_ep[threadIdx.x] += s_ep[threadIdx.x + off];
             s_ret[threadIdx.x] += s_ret[threadIdx.x + off];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out4[0] = s_ret[0];
-        out4[1] = (double)s_len[0];
-        out4[2] = (double)s_ep[0];
-        out4[3] = n_steps;
+        atomicAdd(acc + 0, s_len[0]);
+        atomicAdd(acc + 1, s_ep[0]);
+        atomicAdd(reinterpret_cast<double*>(acc + 2), s_ret[0]);
     }
 }
 
-// set_state support: the touched lanes start a new episode (beyond = None, ep_start = tick).
-__global__ __launch_bounds__(kBlock) void clear_range_kernel(uint8_t* beyond, uint32_t* ep_start, uint64_t first,
-                                                             uint64_t count, uint32_t tick)
+// mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps}; mode 1: remember L as the new base
+// (statistics cleared); mode 2: base = 0 (after reset()).
+__global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned long long* base, int mode, int reward_sign,
+                                      double n_steps, double* out4)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= count) return;
-    if (beyond) beyond[first + i] = 0;
-    ep_start[first + i] = tick;
+    if (mode == 1) {
+        base[0] = acc[0];
+        return;
+    }
+    if (mode == 2) {
+        base[0] = 0;
+        return;
+    }
+    const double len = (double)(acc[0] - base[0]);
+    out4[0] = reward_sign != 0 ? reward_sign * len : *reinterpret_cast<const double*>(acc + 2);
+    out4[1] = len;
+    out4[2] = (double)acc[1];
+    out4[3] = n_steps;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -445,19 +466,18 @@ hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, u
     return hipGetLastError();
 }
 
-hipError_t launch_stats_reduce(const unsigned long long* block_stats, uint32_t n_blocks, double n_steps, double* out4,
-                               hipStream_t stream)
+hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
 {
-    hipLaunchKernelGGL(stats_reduce_kernel, dim3(1), dim3(kBlock), 0, stream, block_stats, n_blocks, n_steps, out4);
-    return hipGetLastError();
-}
-
-hipError_t launch_clear_beyond_range(uint8_t* beyond, uint32_t* ep_start, uint64_t first, uint64_t count, uint32_t tick,
-                                     hipStream_t stream)
-{
-    if (count == 0) return hipSuccess;
-    const uint32_t grid = (uint32_t)((count + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(clear_range_kernel, dim3(grid), dim3(kBlock), 0, stream, beyond, ep_start, first, count, tick);
+    hipError_t err = hipMemsetAsync(a.acc, 0, 3 * sizeof(unsigned long long), stream);
+    if (err != hipSuccess) return err;
+    if (mode != 2) {
+        const uint64_t work = a.track ? a.n : 0; // without GYMRS_TRACK_STATS ep_start carries no statistics
+        uint32_t grid = (uint32_t)((work + kBlock - 1) / kBlock);
+        grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+        hipLaunchKernelGGL(stats_accumulate_kernel, dim3(grid), dim3(kBlock), 0, stream, a.ep_start, work, a.epoch,
+                           a.block_stats, a.track ? a.n_blocks : 0u, a.acc);
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(1), 0, stream, a.acc, a.base, mode, a.reward_sign, a.n_steps, a.out4);
     return hipGetLastError();
 }
 

@@ -123,6 +123,10 @@ GYMRS_HD void sincos_quadrant(int k, float sr, float cr, float* s, float* c)
 // Full-range sin & cos.
 GYMRS_HD void sincosf_(float x, float* s, float* c)
 {
+    if ((f2u(x) & 0x7fffffffu) <= 0x3f490fdbu) { // |x| <= pi/4: no reduction, no quadrant fix-up
+        sincos_poly(x, s, c);                    // (bit-identical to the general path with k = 0)
+        return;
+    }
     float r;
     int k = rem_pio2f(x, &r);
     float sr, cr;

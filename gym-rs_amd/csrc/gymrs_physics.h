@@ -29,11 +29,23 @@ GYMRS_HD float clipf(float v, float l, float r)
     return v;
 }
 
+// a / b for a lane-uniform divisor b whose reciprocal rb = fl32(1/b) was rounded once on the host:
+// one multiply and two fma (Markstein's correction) instead of the 10-instruction IEEE division
+// sequence.  For finite, normal operands this returns the correctly rounded quotient, i.e. the same
+// value as a / b; it is written out so that gfx950 and x86 execute the identical three operations.
+GYMRS_HD float div_by_uniform(float a, float b, float rb)
+{
+    const float q = a * rb;
+    const float e = fmaf_(-b, q, a);
+    return fmaf_(e, rb, q);
+}
+
 // ---------------------------------------------------------------------------------------------
 // CartPole
 struct CartPoleConsts {
     float gravity, masspole, length, force_mag, tau;
     float total_mass;      // masspole + masscart          cartpole.rs:146-148
+    float inv_total_mass;  // fl32(1 / total_mass), for div_by_uniform
     float polemass_length; // masspole + length (sic, Q1)  cartpole.rs:150-152
     float four_thirds;     // 4.0/3.0                      cartpole.rs:427
     float theta_thr, x_thr;
@@ -50,6 +62,7 @@ inline CartPoleConsts make_consts(const gymrs_cartpole_params& p)
     c.force_mag = (float)p.force_mag;
     c.tau = (float)p.tau;
     c.total_mass = (float)(p.masspole + p.masscart);
+    c.inv_total_mass = (float)(1.0 / (double)c.total_mass);
     c.polemass_length = (float)(p.masspole + p.length); // the reference ADDS; do not "fix"
     c.four_thirds = (float)(4.0 / 3.0);
     c.theta_thr = (float)p.theta_threshold_radians;
@@ -67,13 +80,13 @@ GYMRS_HD bool cartpole_advance(const CartPoleConsts& c, float& x, float& x_dot, 
     float sintheta, costheta;
     sincosf_(theta, &sintheta, &costheta); // :420-421
     // :423-424  temp = (force + polemass_length * theta_dot^2 * sintheta) / total_mass
-    const float temp = fmaf_(c.polemass_length * (theta_dot * theta_dot), sintheta, force) / c.total_mass;
+    const float temp = div_by_uniform(fmaf_(c.polemass_length * (theta_dot * theta_dot), sintheta, force), c.total_mass, c.inv_total_mass);
     // :425-428  thetaacc = (g*sin - cos*temp) / (length * (4/3 - masspole*cos^2/total_mass))
     const float num = fmaf_(-costheta, temp, c.gravity * sintheta);
-    const float den = c.length * (c.four_thirds - (c.masspole * (costheta * costheta)) / c.total_mass);
+    const float den = c.length * (c.four_thirds - div_by_uniform(c.masspole * (costheta * costheta), c.total_mass, c.inv_total_mass));
     const float thetaacc = num / den;
     // :429  xacc = temp - polemass_length * thetaacc * costheta / total_mass
-    const float xacc = temp - ((c.polemass_length * thetaacc) * costheta) / c.total_mass;
+    const float xacc = temp - div_by_uniform((c.polemass_length * thetaacc) * costheta, c.total_mass, c.inv_total_mass);
     if (c.integrator == 0) { // :431-435 Euler: x and theta advance with the OLD velocities
         x = fmaf_(c.tau, x_dot, x);
         x_dot = fmaf_(c.tau, xacc, x_dot);

@@ -209,6 +209,7 @@ class Twin:
         L.twin_get_obs.argtypes = [C.c_void_p, C.c_void_p]
         L.twin_get_result.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.twin_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.twin_stats_clear.argtypes = [C.c_void_p]
         L.twin_invalid_count.restype = C.c_uint64
         L.twin_invalid_count.argtypes = [C.c_void_p]
         L.twin_fill_actions.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
@@ -286,6 +287,9 @@ class TwinEngine:
         out = (C.c_double * 4)()
         self.lib.twin_stats(self.h, out)
         return np.array(out[:])
+
+    def stats_clear(self):
+        self.lib.twin_stats_clear(self.h)
 
     def invalid_count(self) -> int:
         return self.lib.twin_invalid_count(self.h)

@@ -129,6 +129,19 @@ void twin_reset(twin_engine* e, uint64_t seed, const float* bounds)
         e->ep_ret[i] = 0.0f;
     }
     e->tick += 1;
+    // a reset discards the open episodes and starts the statistics afresh
+    e->sum_return = 0;
+    e->n_steps = 0;
+    e->sum_length = 0;
+    e->n_episodes = 0;
+}
+
+void twin_stats_clear(twin_engine* e)
+{
+    e->sum_return = 0;
+    e->n_steps = 0;
+    e->sum_length = 0;
+    e->n_episodes = 0;
 }
 
 // One engine step over host action arrays (u8, or f32 for Pendulum).
@@ -211,8 +224,6 @@ void twin_set_state(twin_engine* e, const float* in)
     const int d = state_dim(e);
     for (int j = 0; j < d; ++j) std::memcpy(e->s[j].data(), in + (size_t)j * e->n, e->n * sizeof(float));
     for (uint64_t i = 0; i < e->n; ++i) {
-        e->beyond[i] = 0;
-        e->ep_start[i] = (uint32_t)e->tick;
         if (e->kind == GYMRS_PENDULUM) sincosf_(e->s[0][i], &e->obs_sin[i], &e->obs_cos[i]);
     }
 }

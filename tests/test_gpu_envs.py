@@ -22,6 +22,7 @@ def test_cartpole_env_surface_and_kat(gymrs, golden):
     assert info2 is None and obs2 == obs  # same seed, same state
     for tr in golden("cartpole")["trajectories"]:
         policy = {"always_1": lambda t: 1, "always_0": lambda t: 0, "alternate_1_0": lambda t: (t + 1) % 2}[tr["policy"]]
+        env.reset(seed=0)  # clears steps_beyond_terminated (cartpole.rs:504); assigning `state` does not
         env.state = gymrs.CartPoleObservation(*tr["start"])
         t, total = 0, 0.0
         while True:
@@ -35,6 +36,7 @@ def test_cartpole_env_surface_and_kat(gymrs, golden):
         assert ar.observation.to_vec() == pytest.approx(tr["final"], rel=2e-4)
     # stepping past termination pays 1.0 once, then 0.0 (cartpole.rs:455-464)
     bt = golden("cartpole")["beyond_terminated"]
+    env.reset(seed=0)
     env.state = gymrs.CartPoleObservation(*bt["start"])
     rewards = [env.step(bt["action"]).reward for _ in bt["rewards"]]
     assert rewards == bt["rewards"]

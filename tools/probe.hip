@@ -1,0 +1,156 @@
+// tools/probe.hip — developer micro-benchmarks (not part of the product or the tests).
+// Measures, on the box it runs on, (a) the streaming floor for the CartPole step's access pattern
+// (same arrays, same bytes, trivial arithmetic), one tile per workgroup and a grid-stride persistent
+// form; (b) the engine's step kernel under different flags / lanes-per-thread through the C ABI.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <functional>
+#include "gymrs_amd.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <int V> struct alignas(4 * V) F { float v[V]; };
+template <int V> struct alignas(V) B { unsigned char v[V]; };
+
+// one tile per workgroup: read 4 f32 arrays + u8 action, write 4 f32 + f32 reward + u8 done
+template <int V>
+__global__ __launch_bounds__(256) void copy_tile(float* s0, float* s1, float* s2, float* s3, const unsigned char* act,
+                                                 float* rew, unsigned char* done, size_t n)
+{
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i + V > n) return;
+    F<V> a = *(F<V>*)(s0 + i), b = *(F<V>*)(s1 + i), c = *(F<V>*)(s2 + i), d = *(F<V>*)(s3 + i);
+    B<V> u = *(const B<V>*)(act + i);
+    F<V> r; B<V> dn;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        float f = u.v[k] ? 1.0f : -1.0f;
+        a.v[k] += 0.02f * b.v[k]; b.v[k] += 0.02f * f; c.v[k] += 0.02f * d.v[k]; d.v[k] -= 0.02f * f;
+        r.v[k] = 1.0f; dn.v[k] = a.v[k] > 2.4f;
+    }
+    *(F<V>*)(s0 + i) = a; *(F<V>*)(s1 + i) = b; *(F<V>*)(s2 + i) = c; *(F<V>*)(s3 + i) = d;
+    *(F<V>*)(rew + i) = r; *(B<V>*)(done + i) = dn;
+}
+
+// persistent grid-stride form with a register prefetch of the next tile
+template <int V>
+__global__ __launch_bounds__(256) void copy_persist(float* s0, float* s1, float* s2, float* s3, const unsigned char* act,
+                                                    float* rew, unsigned char* done, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256 * V;
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i + V > n) return;
+    F<V> a = *(F<V>*)(s0 + i), b = *(F<V>*)(s1 + i), c = *(F<V>*)(s2 + i), d = *(F<V>*)(s3 + i);
+    B<V> u = *(const B<V>*)(act + i);
+    while (true) {
+        size_t j = i + stride;
+        bool more = j + V <= n;
+        F<V> na, nb, nc, nd; B<V> nu;
+        if (more) { na = *(F<V>*)(s0 + j); nb = *(F<V>*)(s1 + j); nc = *(F<V>*)(s2 + j); nd = *(F<V>*)(s3 + j); nu = *(const B<V>*)(act + j); }
+        F<V> r; B<V> dn;
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            float f = u.v[k] ? 1.0f : -1.0f;
+            a.v[k] += 0.02f * b.v[k]; b.v[k] += 0.02f * f; c.v[k] += 0.02f * d.v[k]; d.v[k] -= 0.02f * f;
+            r.v[k] = 1.0f; dn.v[k] = a.v[k] > 2.4f;
+        }
+        *(F<V>*)(s0 + i) = a; *(F<V>*)(s1 + i) = b; *(F<V>*)(s2 + i) = c; *(F<V>*)(s3 + i) = d;
+        *(F<V>*)(rew + i) = r; *(B<V>*)(done + i) = dn;
+        if (!more) break;
+        a = na; b = nb; c = nc; d = nd; u = nu; i = j;
+    }
+}
+
+static float time_launches(hipStream_t st, int iters, const std::function<void()>& fn)
+{
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 200; ++i) fn();
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e3f / iters;
+}
+
+#include <functional>
+
+int main(int argc, char** argv)
+{
+    size_t n = (argc > 1) ? (size_t)atoll(argv[1]) : (1u << 20);
+    int iters = (argc > 2) ? atoi(argv[2]) : 2000;
+    CK(hipSetDevice(0));
+    hipStream_t st;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    float *s[4], *rew; unsigned char *act, *done;
+    for (auto& p : s) { CK(hipMalloc(&p, n * 4)); CK(hipMemset(p, 0, n * 4)); }
+    CK(hipMalloc(&rew, n * 4)); CK(hipMalloc(&act, n * 32)); CK(hipMalloc(&done, n));
+    CK(hipMemset(act, 1, n * 32));
+    const double bytes = 38.0 * n;
+    printf("n = %zu lanes, %d launches per measurement, algorithmic bytes per launch = %.1f MB\n", n, iters, bytes / 1e6);
+    auto report = [&](const char* name, float us) { printf("%-44s %8.2f us/launch  %7.1f GB/s  frac(8TB/s) %.3f\n", name, us, bytes / us / 1e3, bytes / us / 1e3 / 8000.0); fflush(stdout); };
+
+#define TILE(V) report("copy_tile V=" #V, time_launches(st, iters, [&] { hipLaunchKernelGGL(copy_tile<V>, dim3((n + 256 * V - 1) / (256 * V)), dim3(256), 0, st, s[0], s[1], s[2], s[3], act, rew, done, n); }))
+    TILE(1); TILE(2); TILE(4);
+#define PERS(V, G) report("copy_persist V=" #V " grid=" #G, time_launches(st, iters, [&] { hipLaunchKernelGGL(copy_persist<V>, dim3(G), dim3(256), 0, st, s[0], s[1], s[2], s[3], act, rew, done, n); }))
+    PERS(1, 512); PERS(1, 1024); PERS(1, 2048); PERS(2, 512); PERS(2, 1024); PERS(4, 256); PERS(4, 512);
+
+    // the engine's kernels through the C ABI
+    const uint32_t flagsets[] = {0u, GYMRS_AUTO_RESET, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS};
+    const char* fnames[] = {"flags=0", "AUTO", "AUTO|STATS"};
+    for (int kind = 0; kind < 3; ++kind) {
+        const size_t asz = kind == 2 ? 4 : 1;
+        for (int f = 0; f < 3; ++f) {
+            for (int vec : {1, 2, 4}) {
+                gymrs_engine* e = nullptr;
+                if (gymrs_engine_create((gymrs_env_kind)kind, n, 0, 0, nullptr, flagsets[f], &e) != GYMRS_OK) { printf("create failed: %s\n", gymrs_last_error()); return 1; }
+                gymrs_set_stream(e, st);
+                gymrs_set_tuning(e, vec, 0);
+                gymrs_reset(e, 1, 0, nullptr, nullptr);
+                for (int b = 0; b < 8; ++b) gymrs_fill_actions(e, act + (size_t)b * n * asz, 1, b);
+                gymrs_step_many(e, act, n * asz, 8, 300, 0);
+                CK(hipStreamSynchronize(st));
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0, st));
+                gymrs_step_many(e, act, n * asz, 8, iters, 0);
+                CK(hipEventRecord(e1, st));
+                CK(hipStreamSynchronize(st));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                char name[96]; snprintf(name, sizeof name, "engine kind=%d %s vec=%d", kind, fnames[f], vec);
+                const double b2 = (kind == 0 ? 38.0 : kind == 1 ? 22.0 : 37.0) * n;
+                float us = ms * 1e3f / iters;
+                printf("%-44s %8.2f us/launch  %7.1f GB/s  frac(8TB/s) %.3f\n", name, us, b2 / us / 1e3, b2 / us / 1e3 / 8000.0); fflush(stdout);
+                gymrs_engine_destroy(e);
+            }
+        }
+    }
+    // two half-batch engines on two streams (kernel overlap hides ramp/drain + the dependent-kernel boundary)
+    for (int parts : {2, 4}) {
+        std::vector<gymrs_engine*> es(parts); std::vector<hipStream_t> ss(parts);
+        size_t np = n / parts;
+        for (int p = 0; p < parts; ++p) {
+            CK(hipStreamCreateWithFlags(&ss[p], hipStreamNonBlocking));
+            gymrs_engine_create(GYMRS_CARTPOLE, np, p * np, 0, nullptr, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, &es[p]);
+            gymrs_set_stream(es[p], ss[p]); gymrs_set_tuning(es[p], 2, 0); gymrs_reset(es[p], 1, 0, nullptr, nullptr);
+            for (int b = 0; b < 8; ++b) gymrs_fill_actions(es[p], act + (size_t)b * n + p * np, 1, b);
+        }
+        auto run = [&](int k) { for (int t = 0; t < k; ++t) for (int p = 0; p < parts; ++p) gymrs_step(es[p], act + (size_t)(t % 8) * n + p * np); };
+        run(300);
+        for (int p = 0; p < parts; ++p) CK(hipStreamSynchronize(ss[p]));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, ss[0]));
+        run(iters);
+        for (int p = 1; p < parts; ++p) { hipEvent_t j; CK(hipEventCreateWithFlags(&j, hipEventDisableTiming)); CK(hipEventRecord(j, ss[p])); CK(hipStreamWaitEvent(ss[0], j, 0)); }
+        CK(hipEventRecord(e1, ss[0]));
+        for (int p = 0; p < parts; ++p) CK(hipStreamSynchronize(ss[p]));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        char name[96]; snprintf(name, sizeof name, "cartpole AUTO|STATS vec=2, %d streams", parts);
+        report(name, ms * 1e3f / iters);
+        for (auto e : es) gymrs_engine_destroy(e);
+    }
+    return 0;
+}
