@@ -21,13 +21,14 @@ struct StepArgs {
     uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
     uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
     float* ep_ret;      // Pendulum with GYMRS_TRACK_STATS: running episode return
-    unsigned long long* block_stats; // [n_blocks][2]: finished episodes, sum of returns (f64 bits; Pendulum only)
+    unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1
     uint64_t n;         // lanes in this engine
     uint64_t gid0;      // global id of lane 0
     uint64_t seed;
     uint64_t tick;
     float lo[4], hi[4]; // reset sampling box
+    uint32_t prio_div;  // tuning experiment: 0 = off, else wave priority = 3 - (blockIdx / prio_div) % 4
 };
 
 struct ResetArgs {
@@ -47,7 +48,7 @@ struct ResetArgs {
 // Number of workgroups step_kernel uses for n lanes at `vec` lanes per work-item.
 inline uint32_t step_grid(uint64_t n, int vec) { return (uint32_t)((n + (uint64_t)kBlock * vec - 1) / ((uint64_t)kBlock * vec)); }
 
-hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
+hipError_t launch_step(gymrs_env_kind kind, int vec, int tiles, uint32_t flags, const StepArgs& a, const void* consts,
                        hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,

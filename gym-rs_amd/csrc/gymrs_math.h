@@ -77,18 +77,22 @@ GYMRS_HD int rem_pio2f(float x, float* r_out)
         return 0;
     }
     // Payne-Hanek.  |x| = m * 2^e with m a 24-bit integer, e >= 5.
-    const uint32_t T[8] = {0xa2f9836eu, 0x4e441529u, 0xfc2757d1u, 0xf534ddc0u,
-                           0xdb629599u, 0x3c439041u, 0xfe5163abu, 0xdebbc561u}; // 2/pi, 256 bits
+    // 2/pi = 0.a2f9836e 4e441529 fc2757d1 f534ddc0 db629599 3c439041 fe5163ab (hex).  The words are
+    // picked with selects, not from a table in memory: a table load would put a vmcnt(0) wait into
+    // the kernels' hot loop even though this branch is almost never taken.
     const uint32_t m = (ax & 0x007fffffu) | 0x00800000u;
     const int e = (int)(ax >> 23) - 150;
     // Bits of 2/pi above position s contribute multiples of 4 to x*(2/pi): skip them.
-    const int s = e - 2;
-    const int i = s >> 5, sh = s & 31;
+    const int s = e - 2;            // 3 <= s <= 102
+    const int i = s >> 5, sh = s & 31; // i in 0..3
+    const uint32_t t0 = i == 0 ? 0xa2f9836eu : i == 1 ? 0x4e441529u : i == 2 ? 0xfc2757d1u : 0xf534ddc0u;
+    const uint32_t t1 = i == 0 ? 0x4e441529u : i == 1 ? 0xfc2757d1u : i == 2 ? 0xf534ddc0u : 0xdb629599u;
+    const uint32_t t2 = i == 0 ? 0xfc2757d1u : i == 1 ? 0xf534ddc0u : i == 2 ? 0xdb629599u : 0x3c439041u;
+    const uint32_t t3 = i == 0 ? 0xf534ddc0u : i == 1 ? 0xdb629599u : i == 2 ? 0x3c439041u : 0xfe5163abu;
     uint32_t w[3];
-    for (int k = 0; k < 3; ++k) {
-        uint64_t pair = ((uint64_t)T[i + k] << 32) | T[i + k + 1];
-        w[k] = (uint32_t)(pair >> (32 - sh));
-    }
+    w[0] = (uint32_t)((((uint64_t)t0 << 32) | t1) >> (32 - sh));
+    w[1] = (uint32_t)((((uint64_t)t1 << 32) | t2) >> (32 - sh));
+    w[2] = (uint32_t)((((uint64_t)t2 << 32) | t3) >> (32 - sh));
     // P = (m * W) mod 2^96, W = w0:w1:w2 ; x*(2/pi) mod 4 = P / 2^94
     uint64_t p2 = (uint64_t)m * w[2];
     uint64_t p1 = (uint64_t)m * w[1] + (p2 >> 32);
@@ -120,6 +124,30 @@ GYMRS_HD void sincos_quadrant(int k, float sr, float cr, float* s, float* c)
     *c = u2f(f2u(b) ^ sb);
 }
 
+// Branch-free sin & cos for |x| < 2^28 * pi/2 (the Cody-Waite range of rem_pio2f).  Produces the
+// same bits as sincosf_ on that range (for |x| <= pi/4: fn = 0, r = x exactly), so a kernel may use
+// it for a whole wave whenever every lane is in range, without changing any result.
+GYMRS_HD void sincos_medium(float x, float* s, float* c)
+{
+    const double invpio2 = 0x1.45f306dc9c883p-1;
+    const double pio2_hi = 0x1.921fb54442d18p+0;
+    const double pio2_lo = 0x1.1a62633145c07p-54;
+    const double xd = (double)x;
+    const double fn = __builtin_rint(xd * invpio2);
+    double rd = fma_(-fn, pio2_hi, xd);
+    rd = fma_(-fn, pio2_lo, rd);
+    float sr, cr;
+    sincos_poly((float)rd, &sr, &cr);
+    sincos_quadrant((int)fn, sr, cr, s, c);
+}
+GYMRS_HD bool in_small_range(float x) { return (f2u(x) & 0x7fffffffu) <= 0x3f490fdbu; }  // |x| <= fl32(pi/4)
+GYMRS_HD bool in_medium_range(float x) { return (f2u(x) & 0x7fffffffu) < 0x4dc90fdbu; }  // |x| < 2^28*pi/2
+
+// How a caller wants sin/cos evaluated.  All three give identical bits where their domains overlap.
+struct SinCosGeneral { static GYMRS_HD void eval(float x, float* s, float* c); };
+struct SinCosSmall { static GYMRS_HD void eval(float x, float* s, float* c) { sincos_poly(x, s, c); } };
+struct SinCosMedium { static GYMRS_HD void eval(float x, float* s, float* c) { sincos_medium(x, s, c); } };
+
 // Full-range sin & cos.
 GYMRS_HD void sincosf_(float x, float* s, float* c)
 {
@@ -133,6 +161,8 @@ GYMRS_HD void sincosf_(float x, float* s, float* c)
     sincos_poly(r, &sr, &cr);
     sincos_quadrant(k, sr, cr, s, c);
 }
+
+GYMRS_HD void SinCosGeneral::eval(float x, float* s, float* c) { sincosf_(x, s, c); }
 
 GYMRS_HD float cosf_(float x)
 {

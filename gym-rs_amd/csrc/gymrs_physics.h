@@ -73,12 +73,15 @@ inline CartPoleConsts make_consts(const gymrs_cartpole_params& p)
 }
 
 // One step of the dynamics + termination test.  Returns done.  (cartpole.rs:408-453)
+// SC selects how sin/cos are evaluated (gymrs_math.h); every choice gives the same bits on its domain.
+// INTEG: -1 = read c.integrator at run time, 0 = Euler, 1 = semi-implicit (lets a kernel hoist the choice).
+template <class SC = SinCosGeneral, int INTEG = -1>
 GYMRS_HD bool cartpole_advance(const CartPoleConsts& c, float& x, float& x_dot, float& theta, float& theta_dot,
                                uint32_t action)
 {
     const float force = (action == 1u) ? c.force_mag : -c.force_mag; // :414-418
     float sintheta, costheta;
-    sincosf_(theta, &sintheta, &costheta); // :420-421
+    SC::eval(theta, &sintheta, &costheta); // :420-421
     // :423-424  temp = (force + polemass_length * theta_dot^2 * sintheta) / total_mass
     const float temp = div_by_uniform(fmaf_(c.polemass_length * (theta_dot * theta_dot), sintheta, force), c.total_mass, c.inv_total_mass);
     // :425-428  thetaacc = (g*sin - cos*temp) / (length * (4/3 - masspole*cos^2/total_mass))
@@ -87,7 +90,7 @@ GYMRS_HD bool cartpole_advance(const CartPoleConsts& c, float& x, float& x_dot, 
     const float thetaacc = num / den;
     // :429  xacc = temp - polemass_length * thetaacc * costheta / total_mass
     const float xacc = temp - div_by_uniform((c.polemass_length * thetaacc) * costheta, c.total_mass, c.inv_total_mass);
-    if (c.integrator == 0) { // :431-435 Euler: x and theta advance with the OLD velocities
+    if (INTEG == 0 || (INTEG < 0 && c.integrator == 0)) { // :431-435 Euler: x and theta advance with the OLD velocities
         x = fmaf_(c.tau, x_dot, x);
         x_dot = fmaf_(c.tau, xacc, x_dot);
         theta = fmaf_(c.tau, theta_dot, theta);
@@ -145,11 +148,14 @@ inline MountainCarConsts make_consts(const gymrs_mountain_car_params& p)
 }
 
 // mountain_car.rs:408-423.  Returns done.
+template <class SC = SinCosGeneral>
 GYMRS_HD bool mountain_car_advance(const MountainCarConsts& c, float& position, float& velocity, uint32_t action)
 {
     // :411-412  velocity += (action - 1) * force + cos(3 * position) * (-gravity)
     const float push = ((float)action - 1.0f) * c.force;
-    velocity = velocity + fmaf_(cosf_(3.0f * position), -c.gravity, push);
+    float sin3p, cos3p;
+    SC::eval(3.0f * position, &sin3p, &cos3p);
+    velocity = velocity + fmaf_(cos3p, -c.gravity, push);
     velocity = clipf(velocity, -c.max_speed, c.max_speed); // :413
     position = position + velocity;                        // :415
     position = clipf(position, c.min_position, c.max_position); // :416
@@ -199,12 +205,15 @@ GYMRS_HD float angle_normalize(float x)
 }
 
 // Returns the reward (-cost, from the OLD state); never terminates.
+template <class SC = SinCosGeneral>
 GYMRS_HD float pendulum_advance(const PendulumConsts& c, float& theta, float& theta_dot, float action)
 {
     const float u = clipf(action, -c.max_torque, c.max_torque);
     const float an = angle_normalize(theta);
     const float cost = fmaf_(0.001f, u * u, fmaf_(0.1f, theta_dot * theta_dot, an * an));
-    const float acc = fmaf_(c.c_sin, sinf_(theta), c.c_u * u);
+    float sin_th, cos_th;
+    SC::eval(theta, &sin_th, &cos_th);
+    const float acc = fmaf_(c.c_sin, sin_th, c.c_u * u);
     float nthd = fmaf_(acc, c.dt, theta_dot);
     nthd = clipf(nthd, -c.max_speed, c.max_speed);
     theta = fmaf_(nthd, c.dt, theta); // semi-implicit: uses the NEW theta_dot
