@@ -54,9 +54,6 @@ struct gymrs_engine {
     uint64_t n = 0, gid0 = 0;
     int device = 0;
     uint32_t flags = 0;
-    int vec = 4;
-    int tiles = 1;
-    uint32_t prio_div = 0;
     int state_dim = 0, obs_dim = 0;
     union {
         CartPoleConsts cp;
@@ -136,7 +133,6 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
         a.lo[j] = e->lo[j];
         a.hi[j] = e->hi[j];
     }
-    a.prio_div = e->prio_div;
     return a;
 }
 
@@ -400,7 +396,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->truncated, npad));
     chk(dev_alloc(&e->beyond, npad));
     chk(dev_alloc(&e->ep_start, npad));
-    e->n_stat_blocks = step_grid(n_envs, 1) * (kBlock / 64); // one statistics slot per wavefront
+    e->n_stat_blocks = step_grid(n_envs) * (kBlock / 64); // one statistics slot per wavefront
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
@@ -455,16 +451,12 @@ gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream)
     return GYMRS_OK;
 }
 
-gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int tiles_and_prio)
+gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
-    if (lanes_per_thread != 1 && lanes_per_thread != 2 && lanes_per_thread != 4)
-        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 1, 2 or 4");
-    const int tiles = (tiles_and_prio & 0xff) ? (tiles_and_prio & 0xff) : 1;
-    if (tiles != 1 && tiles != 2 && tiles != 4) return fail(GYMRS_EINVAL, "gymrs_set_tuning: tiles must be 1, 2 or 4");
-    e->vec = lanes_per_thread;
-    e->tiles = tiles;
-    e->prio_div = (uint32_t)tiles_and_prio >> 8;
+    if (lanes_per_thread != 0 && lanes_per_thread != kLanesPerItem)
+        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4 (or 0 = default)");
+    if (reserved != 0) return fail(GYMRS_EINVAL, "gymrs_set_tuning: reserved must be 0");
     return GYMRS_OK;
 }
 
@@ -529,7 +521,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     StepArgs a = step_args(e, actions_dev);
-    HIP_TRY(launch_step(e->kind, e->vec, e->tiles, e->flags, a, consts_ptr(e), e->stream));
+    HIP_TRY(launch_step(e->kind, e->flags, a, consts_ptr(e), e->stream));
     e->tick += 1;
     e->n_steps_total += (double)e->n;
     return GYMRS_OK;
@@ -555,7 +547,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     const char* base = static_cast<const char*>(actions_dev);
     for (uint32_t t = 0; t < n_steps; ++t) {
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
-        HIP_TRY(launch_step(e->kind, e->vec, e->tiles, e->flags, a, consts_ptr(e), e->stream));
+        HIP_TRY(launch_step(e->kind, e->flags, a, consts_ptr(e), e->stream));
         e->tick += 1;
     }
     e->n_steps_total += (double)e->n * (double)n_steps;

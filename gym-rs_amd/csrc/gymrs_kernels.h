@@ -28,7 +28,6 @@ struct StepArgs {
     uint64_t seed;
     uint64_t tick;
     float lo[4], hi[4]; // reset sampling box
-    uint32_t prio_div;  // tuning experiment: 0 = off, else wave priority = 3 - (blockIdx / prio_div) % 4
 };
 
 struct ResetArgs {
@@ -45,11 +44,15 @@ struct ResetArgs {
     float lo[4], hi[4];
 };
 
-// Number of workgroups step_kernel uses for n lanes at `vec` lanes per work-item.
-inline uint32_t step_grid(uint64_t n, int vec) { return (uint32_t)((n + (uint64_t)kBlock * vec - 1) / ((uint64_t)kBlock * vec)); }
+constexpr int kLanesPerItem = 4; // lanes per work-item (one dwordx4 per SoA array)
+// Number of workgroups step_kernel uses for n lanes (1024 lanes per workgroup).
+inline uint32_t step_grid(uint64_t n)
+{
+    const uint64_t per_block = (uint64_t)kBlock * kLanesPerItem;
+    return (uint32_t)((n + per_block - 1) / per_block);
+}
 
-hipError_t launch_step(gymrs_env_kind kind, int vec, int tiles, uint32_t flags, const StepArgs& a, const void* consts,
-                       hipStream_t stream);
+hipError_t launch_step(gymrs_env_kind kind, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);

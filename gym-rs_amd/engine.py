@@ -141,7 +141,7 @@ class BatchedEngine:
     def set_stream(self, hip_stream: int) -> None:
         _check(self._lib, self._lib.gymrs_set_stream(self._h, C.c_void_p(hip_stream)))
 
-    def set_tuning(self, lanes_per_thread: int) -> None:
+    def set_tuning(self, lanes_per_thread: int = 4) -> None:
         _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), 0))
 
     # -- Env::reset ------------------------------------------------------------------------------
