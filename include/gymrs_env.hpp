@@ -1,0 +1,238 @@
+// gymrs_env.hpp — header-only C++ mirror of the reference's trait surface over the C ABI (gymrs_amd.h).
+//
+// The reference is a Rust crate; this image has no Rust toolchain, so the host side above the C ABI is
+// C++ (the reference is compiled code).  Names, argument meaning and error behaviour follow
+//   trait Env / EnvProperties           /root/reference/src/core.rs:25-90
+//   ActionReward, RewardRange           /root/reference/src/core.rs:94-122
+//   Discrete, BoxR                      /root/reference/src/spaces/discrete.rs:12-20, box_r.rs:5-13
+//   CartPoleEnv, CartPoleObservation    /root/reference/src/envs/classical_control/cartpole.rs:51-87,328-349
+//   MountainCarEnv, ...Observation      /root/reference/src/envs/classical_control/mountain_car.rs:46-84,122-128
+// so a test written against gym-rs reads the same here.  A single env is ONE lane of the batched GPU
+// engine (plumbing configuration); `VecEnv` is the batched form the hot path is built for.
+// Errors: the reference panics (assert!/unwrap); here they are C++ exceptions (gymrs::Panic).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <limits>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gymrs_amd.h"
+
+namespace gymrs {
+
+struct Panic : std::runtime_error {
+    gymrs_status status;
+    Panic(gymrs_status s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+inline void check(gymrs_status s)
+{
+    if (s != GYMRS_OK) throw Panic(s, gymrs_last_error());
+}
+
+enum class RenderMode { Human, SingleRgbArray, RgbArray, Ansi, None }; // utils/renderer.rs:83-114 (only None is supported)
+
+struct Discrete { // spaces/discrete.rs:12-20
+    std::size_t n;
+    bool contains(std::size_t value) const { return value < n; }
+    bool operator==(const Discrete& o) const { return n == o.n; }
+};
+template <class T>
+struct BoxR { // spaces/box_r.rs:5-13
+    T low, high;
+};
+struct RewardRange { // core.rs:109-122, default (-inf, inf) core.rs:16-19
+    double lower_bound = -std::numeric_limits<double>::infinity();
+    double upper_bound = std::numeric_limits<double>::infinity();
+};
+template <class Obs, class Info>
+struct ActionReward { // core.rs:94-106
+    Obs observation;
+    double reward;
+    bool done;
+    bool truncated;
+    std::optional<Info> info;
+};
+struct Unit {}; // Rust's ()
+
+struct CartPoleObservation { // cartpole.rs:328-334; Into<Vec<f64>> order :336-349
+    double x, x_dot, theta, theta_dot;
+    std::vector<double> to_vec() const { return {x, x_dot, theta, theta_dot}; }
+    CartPoleObservation operator-() const { return {-x, -x_dot, -theta, -theta_dot}; } // :367-378
+};
+struct MountainCarObservation { // mountain_car.rs:122-128
+    double position, velocity;
+    std::vector<double> to_vec() const { return {position, velocity}; }
+};
+
+// ---- batched form: the shape the hot path is built for ---------------------------------------------
+class VecEnv {
+public:
+    VecEnv(gymrs_env_kind kind, std::uint64_t n_envs, std::uint32_t flags = 0, const void* params = nullptr,
+           std::uint64_t global_env_offset = 0, int device = 0)
+        : kind_(kind), n_(n_envs)
+    {
+        check(gymrs_engine_create(kind, n_envs, global_env_offset, device, params, flags, &e_));
+        int d = 0;
+        float* p[4];
+        check(gymrs_state_ptrs(e_, p, &d));
+        state_dim_ = d;
+    }
+    ~VecEnv() { gymrs_engine_destroy(e_); }
+    VecEnv(const VecEnv&) = delete;
+    VecEnv& operator=(const VecEnv&) = delete;
+
+    std::uint64_t reset(std::optional<std::uint64_t> seed, const float* bounds_low_high = nullptr)
+    {
+        std::uint64_t used = 0;
+        check(gymrs_reset(e_, seed.has_value(), seed.value_or(0), bounds_low_high, &used));
+        return used;
+    }
+    void step_device(const void* actions_dev) { check(gymrs_step(e_, actions_dev)); } // async
+    void step_host(const void* actions_host)
+    {
+        check(gymrs_step_host(e_, actions_host));
+        check(gymrs_sync(e_));
+    }
+    void sync() { check(gymrs_sync(e_)); }
+    std::vector<float> state(std::uint64_t first, std::uint64_t count)
+    {
+        std::vector<float> out(count * state_dim_);
+        check(gymrs_get_state(e_, first, count, out.data()));
+        return out;
+    }
+    void set_state(std::uint64_t first, std::uint64_t count, const float* soa) { check(gymrs_set_state(e_, first, count, soa)); }
+    void result(std::uint64_t first, std::uint64_t count, float* reward, std::uint8_t* done, std::uint8_t* truncated)
+    {
+        check(gymrs_get_step_result(e_, first, count, reward, done, truncated));
+    }
+    gymrs_engine* handle() { return e_; }
+    std::uint64_t size() const { return n_; }
+    int state_dim() const { return state_dim_; }
+
+private:
+    gymrs_env_kind kind_;
+    std::uint64_t n_;
+    gymrs_engine* e_ = nullptr;
+    int state_dim_ = 0;
+};
+
+// ---- single envs with the reference's surface ------------------------------------------------------
+class CartPoleEnv {
+public:
+    using Action = std::size_t;
+    using Observation = CartPoleObservation;
+    explicit CartPoleEnv(RenderMode mode = RenderMode::None) : env_(make(mode)) {}
+
+    ActionReward<Observation, Unit> step(Action action) // Env::step, cartpole.rs:398-483
+    {
+        if (!action_space().contains(action)) throw Panic(GYMRS_EACTION, std::to_string(action) + " usize invalid"); // :402-406
+        const std::uint8_t a = static_cast<std::uint8_t>(action);
+        env_.step_host(&a);
+        float r;
+        std::uint8_t d;
+        env_.result(0, 1, &r, &d, nullptr);
+        return {state(), r, d != 0, false, Unit{}}; // truncated: false, info: Some(()) (:480-481)
+    }
+    std::pair<Observation, std::optional<Unit>> reset(std::optional<std::uint64_t> seed, bool return_info,
+                                                       std::optional<BoxR<Observation>> options) // :485-516
+    {
+        float b[8];
+        if (options) {
+            const auto lo = options->low.to_vec(), hi = options->high.to_vec();
+            for (int j = 0; j < 4; ++j) {
+                b[j] = static_cast<float>(lo[j]);
+                b[4 + j] = static_cast<float>(hi[j]);
+            }
+        }
+        env_.reset(seed, options ? b : nullptr);
+        return {state(), return_info ? std::optional<Unit>(Unit{}) : std::nullopt};
+    }
+    void render(RenderMode) {} // renderer.rs:52-62: nothing is drawn under RenderMode::None
+    void close() {}
+    Observation state()
+    {
+        const auto s = env_.state(0, 1);
+        return {s[0], s[1], s[2], s[3]};
+    }
+    void set_state(const Observation& o)
+    {
+        const float s[4] = {(float)o.x, (float)o.x_dot, (float)o.theta, (float)o.theta_dot};
+        env_.set_state(0, 1, s);
+    }
+    Discrete action_space() const { return Discrete{2}; } // cartpole.rs:114
+    BoxR<Observation> observation_space() const         // cartpole.rs:105-115
+    {
+        const double inf = std::numeric_limits<double>::infinity();
+        const Observation high{2.4 * 2., inf, (12. * 2. * 3.14159265358979323846 / 360.) * 2., inf};
+        return {-high, high};
+    }
+    RewardRange reward_range() const { return {}; }
+    RenderMode render_mode() const { return RenderMode::None; }
+
+private:
+    static VecEnv make(RenderMode mode)
+    {
+        if (mode != RenderMode::None) throw Panic(GYMRS_EINVAL, "rendering is out of scope: use RenderMode::None");
+        return VecEnv(GYMRS_CARTPOLE, 1);
+    }
+    VecEnv env_;
+};
+
+class MountainCarEnv {
+public:
+    using Action = std::size_t;
+    using Observation = MountainCarObservation;
+    explicit MountainCarEnv(RenderMode mode = RenderMode::None) : env_(make(mode)) {}
+
+    ActionReward<Observation, Unit> step(Action action) // mountain_car.rs:398-435
+    {
+        if (!action_space().contains(action)) throw Panic(GYMRS_EACTION, std::to_string(action) + " (usize) invalid");
+        const std::uint8_t a = static_cast<std::uint8_t>(action);
+        env_.step_host(&a);
+        float r;
+        std::uint8_t d;
+        env_.result(0, 1, &r, &d, nullptr);
+        return {state(), r, d != 0, false, std::nullopt}; // info: None (:433)
+    }
+    std::pair<Observation, std::optional<Unit>> reset(std::optional<std::uint64_t> seed, bool return_info,
+                                                       std::optional<BoxR<Observation>> options) // :464-501
+    {
+        float b[4];
+        if (options) {
+            b[0] = (float)options->low.position;
+            b[1] = (float)options->low.velocity;
+            b[2] = (float)options->high.position;
+            b[3] = (float)options->high.velocity;
+        }
+        env_.reset(seed, options ? b : nullptr);
+        return {state(), return_info ? std::optional<Unit>(Unit{}) : std::nullopt};
+    }
+    void render(RenderMode) {}
+    void close() {}
+    Observation state()
+    {
+        const auto s = env_.state(0, 1);
+        return {s[0], s[1]};
+    }
+    void set_state(const Observation& o)
+    {
+        const float s[2] = {(float)o.position, (float)o.velocity};
+        env_.set_state(0, 1, s);
+    }
+    Discrete action_space() const { return Discrete{3}; }                                    // mountain_car.rs:362
+    BoxR<Observation> observation_space() const { return {{-1.2, -0.07}, {0.6, 0.07}}; }      // :353-364
+
+private:
+    static VecEnv make(RenderMode mode)
+    {
+        if (mode != RenderMode::None) throw Panic(GYMRS_EINVAL, "rendering is out of scope: use RenderMode::None");
+        return VecEnv(GYMRS_MOUNTAIN_CAR, 1);
+    }
+    VecEnv env_;
+};
+
+} // namespace gymrs

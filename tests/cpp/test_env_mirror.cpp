@@ -1,0 +1,98 @@
+// C++ test of the trait mirror (include/gymrs_env.hpp) on a real GPU: reads like a test of the reference
+// crate.  Expected values: SURVEY.md Appendix C (tests/golden/*.json hold the same numbers).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "gymrs_env.hpp"
+
+#define REQUIRE(cond)                                                              \
+    do {                                                                           \
+        if (!(cond)) {                                                             \
+            std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);          \
+            std::exit(1);                                                          \
+        }                                                                          \
+    } while (0)
+
+static bool close_to(double a, double b, double rel) { return std::fabs(a - b) <= rel * std::fmax(std::fabs(b), 1.0); }
+
+int main()
+{
+    using namespace gymrs;
+    {
+        CartPoleEnv env(RenderMode::None);
+        REQUIRE(env.action_space() == Discrete{2});
+        REQUIRE(env.action_space().contains(1) && !env.action_space().contains(2));
+        const auto space = env.observation_space();
+        REQUIRE(space.high.x == 4.8 && std::isinf(space.high.x_dot) && close_to(space.high.theta, 0.41887902047863906, 1e-15));
+        auto [obs, info] = env.reset(64, true, std::nullopt);
+        REQUIRE(info.has_value() && std::fabs(obs.x) < 0.05 && std::fabs(obs.theta_dot) < 0.05);
+        auto [obs2, info2] = env.reset(64, false, std::nullopt);
+        REQUIRE(!info2.has_value() && obs2.x == obs.x && obs2.theta == obs.theta); // same seed, same state
+        // single step from (0.01, 0.02, 0.03, 0.04), action 1: 0.356 (reference), not Gym's 0.215 (Q1)
+        env.set_state({0.01, 0.02, 0.03, 0.04});
+        auto ar = env.step(1);
+        REQUIRE(close_to(ar.observation.x_dot, 0.35615076996399875, 1e-6) && close_to(ar.observation.theta_dot, -0.2430694901285738, 1e-6));
+        REQUIRE(ar.reward == 1.0 && !ar.done && !ar.truncated && ar.info.has_value());
+        // trajectories: always 1 -> 10 steps, always 0 -> 9, alternate 1,0,... -> 60
+        const int expect[3] = {10, 9, 60};
+        for (int p = 0; p < 3; ++p) {
+            env.reset(0, false, std::nullopt);
+            env.set_state({0.01, 0.02, 0.03, 0.04});
+            int t = 0;
+            double total = 0;
+            for (;;) {
+                const std::size_t a = p == 0 ? 1 : p == 1 ? 0 : (t + 1) % 2;
+                auto r = env.step(a);
+                total += r.reward;
+                ++t;
+                if (r.done) break;
+            }
+            REQUIRE(t == expect[p] && total == (double)t);
+        }
+        // stepping past termination: 1.0 once more, then 0.0 (cartpole.rs:455-464)
+        REQUIRE(env.step(1).reward == 0.0);
+        bool panicked = false;
+        try {
+            env.step(2);
+        } catch (const Panic& e) {
+            panicked = e.status == GYMRS_EACTION;
+        }
+        REQUIRE(panicked);
+        // options override the sampling box
+        auto [o3, i3] = env.reset(1, false, BoxR<CartPoleObservation>{{1., 2., 0.1, 5.}, {1.5, 3., 0.2, 6.}});
+        REQUIRE(o3.x >= 1. && o3.x < 1.5 && o3.x_dot >= 2. && o3.theta >= 0.0999 && o3.theta_dot >= 5. && o3.theta_dot < 6.);
+    }
+    {
+        MountainCarEnv env(RenderMode::None);
+        REQUIRE(env.action_space() == Discrete{3});
+        auto [obs, info] = env.reset(1, false, std::nullopt);
+        REQUIRE(obs.position >= -0.6 - 1e-7 && obs.position < -0.4 && obs.velocity == 0.0);
+        env.set_state({-0.5, 0.0});
+        int t = 0;
+        double total = 0;
+        for (;;) {
+            auto r = env.step(env.state().velocity >= 0 ? 2 : 0);
+            total += r.reward;
+            ++t;
+            REQUIRE(!r.info.has_value() && !r.truncated);
+            if (r.done) break;
+        }
+        REQUIRE(t == 124 && total == -124.0);
+        env.set_state({-1.19, -0.07});
+        auto r = env.step(0);
+        REQUIRE(close_to(r.observation.position, -1.2, 1e-6) && r.observation.velocity == 0.0 && !r.done); // wall rule
+    }
+    {
+        // batched form: 4096 lanes, one launch per step, host actions
+        VecEnv env(GYMRS_CARTPOLE, 4096, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS);
+        env.reset(7);
+        std::vector<std::uint8_t> act(4096, 1);
+        for (int t = 0; t < 50; ++t) env.step_host(act.data());
+        double st[4];
+        check(gymrs_stats(env.handle(), st));
+        REQUIRE(st[3] == 4096.0 * 50 && st[2] > 0 && st[0] == st[1]);
+    }
+    std::printf("CPP_MIRROR_OK\n");
+    return 0;
+}

@@ -139,3 +139,19 @@ def test_two_rank_sharding_and_allreduce_gloo(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "SHARD_OK" in res.stdout
+
+
+def test_cpp_trait_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
+    """The C++ host side (include/gymrs_env.hpp) builds against the C ABI with plain g++ (no HIP headers, no
+    torch types in the signatures); without a GPU it must stop with the library's own error, not fall back."""
+    exe = tmp_path / "test_env_mirror"
+    lib_dir = ROOT / "gym-rs_amd"
+    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "test_env_mirror.cpp"),
+                    "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the run is covered by tests/test_gpu_envs.py::test_cpp_trait_mirror")
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert res.returncode != 0 and "no CPU fallback" in (res.stdout + res.stderr)

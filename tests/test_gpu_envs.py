@@ -105,3 +105,18 @@ def test_mutable_physics_fields(gymrs):
     b = env.step(1).observation
     assert b.x_dot > a.x_dot * 1.5
     env.close()
+
+
+def test_cpp_trait_mirror(tmp_path):
+    """include/gymrs_env.hpp (the C++ host side above the C ABI) on the GPU: tests/cpp/test_env_mirror.cpp."""
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    exe = tmp_path / "test_env_mirror"
+    lib_dir = root / "gym-rs_amd"
+    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_env_mirror.cpp"),
+                    "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
+                   check=True, capture_output=True, text=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "CPP_MIRROR_OK" in res.stdout, res.stdout + res.stderr
