@@ -67,6 +67,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--env", choices=sorted(ENVS), default="cartpole")
     ap.add_argument("--n-envs", type=int, default=0, help="lanes per GPU (default: the BASELINE config)")
+    ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4, 8, 16); 0 = engine default")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
@@ -97,7 +98,8 @@ def main() -> int:
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
     if args.env == "pendulum":
         flags |= gymrs.TIME_LIMIT  # it never terminates; episodes end by the 200-step limit only
-    eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags)
+    eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags,
+                              lanes_per_thread=args.vec or None)
     stream = torch.cuda.ExternalStream(eng.stream, device=local_rank)
 
     # synthetic inputs, resident in HBM before the timed region
@@ -181,7 +183,7 @@ def main() -> int:
                 "lanes_per_gpu": n,
                 "total_lanes": n * world,
                 "flags": "AUTO_RESET|TRACK_STATS" + ("|TIME_LIMIT" if args.env == "pendulum" else ""),
-                "lanes_per_work_item": 4,
+                "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
                 "parallelism": f"lane-sharded x{world}, no data-path collective; 1 RCCL all-reduce of 4 f64 per run",
             },

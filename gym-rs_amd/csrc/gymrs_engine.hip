@@ -77,6 +77,8 @@ struct gymrs_engine {
     float* ep_ret = nullptr;
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
+    int vec = 4; // lanes per work-item
+    unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
     double* stats_dev = nullptr;
     unsigned long long* stats_acc = nullptr;  // [3] scratch of the statistics read-out
@@ -129,10 +131,8 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.gid0 = e->gid0;
     a.seed = e->seed;
     a.tick = e->tick;
-    for (int j = 0; j < 4; ++j) {
-        a.lo[j] = e->lo[j];
-        a.hi[j] = e->hi[j];
-    }
+    a.box = make_sample_box(e->lo, e->hi, e->state_dim);
+    a.trace = e->trace;
     return a;
 }
 
@@ -396,7 +396,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->truncated, npad));
     chk(dev_alloc(&e->beyond, npad));
     chk(dev_alloc(&e->ep_start, npad));
-    e->n_stat_blocks = step_grid(n_envs) * (kBlock / 64); // one statistics slot per wavefront
+    e->n_stat_blocks = step_grid(n_envs, 4) * (kBlock / 64); // one statistics slot per wavefront (most waves at vec = 4)
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
@@ -454,9 +454,10 @@ gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream)
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
-    if (lanes_per_thread != 0 && lanes_per_thread != kLanesPerItem)
-        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4 (or 0 = default)");
+    if (lanes_per_thread != 4 && lanes_per_thread != 8 && lanes_per_thread != 16)
+        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4, 8 or 16");
     if (reserved != 0) return fail(GYMRS_EINVAL, "gymrs_set_tuning: reserved must be 0");
+    e->vec = lanes_per_thread;
     return GYMRS_OK;
 }
 
@@ -502,10 +503,7 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     a.gid0 = e->gid0;
     a.seed = e->seed;
     a.tick = e->tick;
-    for (int j = 0; j < 4; ++j) {
-        a.lo[j] = lo[j];
-        a.hi[j] = hi[j];
-    }
+    a.box = make_sample_box(lo, hi, e->state_dim);
     HIP_TRY(launch_reset(e->kind, a, e->stream));
     e->tick += 1;
     e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
@@ -521,7 +519,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     StepArgs a = step_args(e, actions_dev);
-    HIP_TRY(launch_step(e->kind, e->flags, a, consts_ptr(e), e->stream));
+    HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
     e->tick += 1;
     e->n_steps_total += (double)e->n;
     return GYMRS_OK;
@@ -547,7 +545,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     const char* base = static_cast<const char*>(actions_dev);
     for (uint32_t t = 0; t < n_steps; ++t) {
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
-        HIP_TRY(launch_step(e->kind, e->flags, a, consts_ptr(e), e->stream));
+        HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
         e->tick += 1;
     }
     e->n_steps_total += (double)e->n * (double)n_steps;
@@ -782,6 +780,15 @@ gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t see
     HIP_TRY(launch_fill_actions(e->kind, actions_dev, e->n, e->gid0, seed, t, e->max_torque, e->stream));
     return GYMRS_OK;
 }
+
+#ifdef GYMRS_TRACE_TIMES
+// developer hook, not part of the ABI header: device buffer of 8 u64 stamps per wavefront
+gymrs_status gymrs_dev_set_trace(gymrs_engine* e, unsigned long long* buf)
+{
+    e->trace = buf;
+    return GYMRS_OK;
+}
+#endif
 
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed)
 {

@@ -27,7 +27,8 @@ struct StepArgs {
     uint64_t gid0;      // global id of lane 0
     uint64_t seed;
     uint64_t tick;
-    float lo[4], hi[4]; // reset sampling box
+    SampleBox box;      // reset sampling box, prepared on the host (gymrs_philox.h)
+    unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
 };
 
 struct ResetArgs {
@@ -41,18 +42,18 @@ struct ResetArgs {
     uint32_t* ep_start;
     float* ep_ret;
     uint64_t n, gid0, seed, tick;
-    float lo[4], hi[4];
+    SampleBox box;
 };
 
-constexpr int kLanesPerItem = 4; // lanes per work-item (one dwordx4 per SoA array)
-// Number of workgroups step_kernel uses for n lanes (1024 lanes per workgroup).
-inline uint32_t step_grid(uint64_t n)
+// Number of workgroups step_kernel uses for n lanes at `vec` lanes per work-item (4, 8 or 16).
+inline uint32_t step_grid(uint64_t n, int vec)
 {
-    const uint64_t per_block = (uint64_t)kBlock * kLanesPerItem;
+    const uint64_t per_block = (uint64_t)kBlock * vec;
     return (uint32_t)((n + per_block - 1) / per_block);
 }
 
-hipError_t launch_step(gymrs_env_kind kind, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
+hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
+                       hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);

@@ -36,7 +36,17 @@
 
 namespace gymrs {
 
-constexpr int kVec = 4; // lanes per work-item
+
+// Developer instrumentation (tools/probe --trace): per-wave s_memtime stamps at the phase boundaries.
+#ifdef GYMRS_TRACE_TIMES
+#define GYMRS_STAMP(slot_)                                                                                   \
+    do {                                                                                                     \
+        if (a.trace && (threadIdx.x & 63u) == 0)                                                             \
+            a.trace[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define GYMRS_STAMP(slot_) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // vector access helpers
@@ -95,10 +105,7 @@ struct CartPoleT {
         done = cartpole_advance<SinCosSmall, INTEG>(c, st[0], st[1], st[2], st[3], a);
         reward = 1.0f;
     }
-    __device__ static void sample(const u32x4& r, const float* lo, const float* hi, float* st)
-    {
-        cartpole_sample(r, lo, hi, st[0], st[1], st[2], st[3]);
-    }
+    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { cartpole_sample(r, b, st[0], st[1], st[2], st[3]); }
 };
 
 struct MountainCarT {
@@ -123,10 +130,7 @@ struct MountainCarT {
         done = mountain_car_advance<SinCosMedium>(c, st[0], st[1], a);
         reward = -1.0f;
     }
-    __device__ static void sample(const u32x4& r, const float* lo, const float* hi, float* st)
-    {
-        mountain_car_sample(r, lo, hi, st[0], st[1]);
-    }
+    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { mountain_car_sample(r, b, st[0], st[1]); }
 };
 
 struct PendulumT { // spec-derived, not in the reference
@@ -152,30 +156,28 @@ struct PendulumT { // spec-derived, not in the reference
         reward = pendulum_advance<SinCosMedium>(c, st[0], st[1], a);
         done = false;
     }
-    __device__ static void sample(const u32x4& r, const float* lo, const float* hi, float* st)
-    {
-        pendulum_sample(r, lo, hi, st[0], st[1]);
-    }
+    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { pendulum_sample(r, b, st[0], st[1]); }
 };
 
 // ---------------------------------------------------------------------------------------------
-// THE hot kernel: one Env::step() per lane; a work-item owns 4 lanes, a wavefront 256, a workgroup 1024.
-template <class Env, uint32_t FLAGS>
+// THE hot kernel: one Env::step() per lane; a work-item owns VEC lanes, a wavefront 64*VEC, a workgroup 256*VEC.
+template <class Env, int VEC, uint32_t FLAGS>
 struct TileRegs {
     static constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     static constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
     static constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
-    Vec<float, kVec> st[Env::kState];
-    Vec<typename Env::Action, kVec> act;
-    Vec<uint8_t, kVec> beyond;
-    Vec<uint32_t, kVec> ep_start;
-    Vec<float, kVec> ep_ret;
+    Vec<float, VEC> st[Env::kState];
+    Vec<typename Env::Action, VEC> act;
+    Vec<uint8_t, VEC> beyond;
+    Vec<uint32_t, VEC> ep_start;
+    Vec<float, VEC> ep_ret;
 };
 
-template <class Env, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, TileRegs<Env, FLAGS>& d)
+template <class Env, int VEC, uint32_t FLAGS, bool FULL>
+__device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, TileRegs<Env, VEC, FLAGS>& d)
 {
-    using R = TileRegs<Env, FLAGS>;
+    constexpr int kVec = VEC;
+    using R = TileRegs<Env, VEC, FLAGS>;
     using Action = typename Env::Action;
 #pragma unroll
     for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec>(a.s[j], base, a.n, FULL, 0.0f);
@@ -187,19 +189,23 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
 
 // LDS of one workgroup for the auto-reset hand-off: every wavefront uses its own 256-entry segment
 // (list of finished lanes, their fresh states, their finished returns); waves never touch each other's.
-template <class Env>
+template <class Env, int VEC>
 struct ResetLds {
-    static constexpr int kLanes = kBlock * kVec;
+    static constexpr int kLanes = kBlock * VEC;
     uint16_t list[kLanes];
-    float fresh[Env::kState][kLanes];
+    struct alignas(Env::kState * 4) State {
+        float v[Env::kState];
+    };
+    State fresh[kLanes]; // one ds_write/ds_read of 8 or 16 bytes per finished lane
     float ret[Env::kConstReward ? 1 : kLanes];
 };
 
 // The branch-free physics of the 4 lanes of a work-item in one basic block (V = Env variant).
-template <class Env, int V>
-__device__ __forceinline__ void advance_fast_all(const typename Env::Consts& c, float (&ls)[Env::kState][kVec],
-                                                 const typename Env::Action (&la)[kVec], float (&rw)[kVec], bool (&dn)[kVec])
+template <class Env, int VEC, int V>
+__device__ __forceinline__ void advance_fast_all(const typename Env::Consts& c, float (&ls)[Env::kState][VEC],
+                                                 const typename Env::Action (&la)[VEC], float (&rw)[VEC], bool (&dn)[VEC])
 {
+    constexpr int kVec = VEC;
     constexpr int NS = Env::kState;
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
@@ -213,12 +219,13 @@ __device__ __forceinline__ void advance_fast_all(const typename Env::Consts& c, 
 }
 
 // physics + auto-reset selection + stores of one tile whose loads were issued by load_tile
-template <class Env, uint32_t FLAGS, bool FULL>
+template <class Env, int VEC, uint32_t FLAGS, bool FULL>
 __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
-                                            TileRegs<Env, FLAGS>& d, ResetLds<Env>& lds, unsigned long long old_resets,
+                                            TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC>& lds, unsigned long long old_resets,
                                             double old_ret)
 {
-    using R = TileRegs<Env, FLAGS>;
+    constexpr int kVec = VEC;
+    using R = TileRegs<Env, VEC, FLAGS>;
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
     constexpr int NS = Env::kState;
     using Action = typename Env::Action;
@@ -237,6 +244,10 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
     }
     float rw[kVec];
     bool dn[kVec], tr[kVec], need_reset[kVec];
+#ifdef GYMRS_TRACE_TIMES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GYMRS_STAMP(2); // all loads have landed
+#endif
     bool fast = FULL;
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
@@ -247,9 +258,9 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
     }
     if (__all(fast)) { // wave-uniform: the common path
         if (Env::kVariants == 1 || Env::variant(c) == 0)
-            advance_fast_all<Env, 0>(c, ls, la, rw, dn);
+            advance_fast_all<Env, VEC, 0>(c, ls, la, rw, dn);
         else
-            advance_fast_all<Env, 1>(c, ls, la, rw, dn);
+            advance_fast_all<Env, VEC, 1>(c, ls, la, rw, dn);
     } else { // general per-lane code: ragged tail, invalid actions, angles outside the fast range
         uint32_t n_bad = 0, first_bad = 0xffffffffu;
 #pragma unroll
@@ -277,6 +288,7 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
             atomicMin(&a.err[1], first_bad);
         }
     }
+    GYMRS_STAMP(3); // physics done
     Vec<uint8_t, kVec> done, trunc;
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
@@ -325,9 +337,11 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
                 const uint64_t gl = wave_base + list[i];
                 const u32x4 r = draw4(a.seed, a.gid0 + gl, a.tick, kStreamReset);
                 float ns[NS];
-                Env::sample(r, a.lo, a.hi, ns);
+                Env::sample(r, a.box, ns);
+                typename ResetLds<Env, VEC>::State fs;
 #pragma unroll
-                for (int j = 0; j < NS; ++j) lds.fresh[j][wave * LPW + i] = ns[j];
+                for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
+                lds.fresh[wave * LPW + i] = fs;
                 if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick
                 if (STATS && !Env::kConstReward) ret_sum += lds.ret[wave * LPW + i]; // return of the finished episode
             }
@@ -336,8 +350,9 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
 #pragma unroll
             for (int k = 0; k < kVec; ++k) {
                 if (need_reset[k]) {
+                    const typename ResetLds<Env, VEC>::State fs = lds.fresh[wave * LPW + slot[k]];
 #pragma unroll
-                    for (int j = 0; j < NS; ++j) ls[j][k] = lds.fresh[j][wave * LPW + slot[k]];
+                    for (int j = 0; j < NS; ++j) ls[j][k] = fs.v[j];
                     if (STATS && !Env::kConstReward) d.ep_ret.v[k] = 0.0f;
                 }
             }
@@ -353,6 +368,7 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
         }
     }
 
+    GYMRS_STAMP(4); // auto-reset done
     // ---- stores ----
     Vec<float, kVec> reward;
 #pragma unroll
@@ -384,11 +400,16 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
         store_vec<float, kVec>(a.obs_cos, base, a.n, FULL, oc);
         store_vec<float, kVec>(a.obs_sin, base, a.n, FULL, os);
     }
+    GYMRS_STAMP(5); // stores issued
+#ifdef GYMRS_TRACE_TIMES
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
-template <class Env, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env>& lds)
+template <class Env, int VEC, uint32_t FLAGS, bool FULL>
+__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
 {
+    constexpr int kVec = VEC;
     constexpr int LPB = kBlock * kVec;
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
@@ -404,24 +425,29 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
         old_resets = bs[0];
         if (!Env::kConstReward) old_ret = reinterpret_cast<const double*>(bs)[1];
     }
-    TileRegs<Env, FLAGS> d;
-    load_tile<Env, FLAGS, FULL>(a, base, d);
-    finish_tile<Env, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret);
+    GYMRS_STAMP(0);
+    TileRegs<Env, VEC, FLAGS> d;
+    load_tile<Env, VEC, FLAGS, FULL>(a, base, d);
+    GYMRS_STAMP(1);
+    finish_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret);
+    GYMRS_STAMP(6);
 }
 
-// waves_per_eu(4, 8): 4 workgroups of 4 waves per CU is all a 2^20-lane launch needs, so the register
-// allocator may use up to 128 VGPRs instead of spilling to reach 8 waves per SIMD.
-template <class Env, uint32_t FLAGS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void step_kernel(const StepArgs a,
-                                                                                              const typename Env::Consts c)
+// VEC lanes per work-item: 4 (1024 workgroups for 2^20 lanes, 4 waves per SIMD), 8 (2 waves per SIMD) or 16
+// (1 wave per SIMD).  More lanes per wave = fewer waves = fewer per-wave fixed costs (address set-up, the
+// auto-reset Philox pass, which costs the same whether 11 or 45 of its 64 lanes are active) at the price of
+// registers; waves_per_eu lets the allocator use them instead of spilling to chase occupancy.
+template <class Env, int VEC, uint32_t FLAGS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
+    const StepArgs a, const typename Env::Consts c)
 {
-    constexpr int LPB = kBlock * kVec;
-    __shared__ ResetLds<Env> lds;
+    constexpr int LPB = kBlock * VEC;
+    __shared__ ResetLds<Env, VEC> lds;
     // workgroup-uniform: every workgroup but the last runs the unguarded body
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
-        step_block<Env, FLAGS, true>(a, c, lds);
+        step_block<Env, VEC, FLAGS, true>(a, c, lds);
     else
-        step_block<Env, FLAGS, false>(a, c, lds);
+        step_block<Env, VEC, FLAGS, false>(a, c, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
     if (lane >= a.n) return;
     const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
     float ns[Env::kState];
-    Env::sample(r, a.lo, a.hi, ns);
+    Env::sample(r, a.box, ns);
 #pragma unroll
     for (int j = 0; j < Env::kState; ++j) a.s[j][lane] = ns[j];
     if (Env::kHasObsExtra) {
@@ -526,37 +552,49 @@ __global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned lo
 
 // ---------------------------------------------------------------------------------------------
 // launch tables
-template <class Env, uint32_t FLAGS>
+template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
-    hipLaunchKernelGGL((step_kernel<Env, FLAGS>), dim3(step_grid(a.n)), dim3(kBlock), 0, stream, a,
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a,
                        *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }
 
-template <class Env>
+template <class Env, int VEC>
 static hipError_t launch_flags(uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
 {
     constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
     if (!(flags & A)) flags &= ~S; // statistics need auto-reset
     switch (flags & (A | S | T)) {
-    case 0: return launch_one<Env, 0>(a, consts, stream);
-    case A: return launch_one<Env, A>(a, consts, stream);
-    case A | S: return launch_one<Env, A | S>(a, consts, stream);
-    case T: return launch_one<Env, T>(a, consts, stream);
-    case A | T: return launch_one<Env, A | T>(a, consts, stream);
-    case A | S | T: return launch_one<Env, A | S | T>(a, consts, stream);
+    case 0: return launch_one<Env, VEC, 0>(a, consts, stream);
+    case A: return launch_one<Env, VEC, A>(a, consts, stream);
+    case A | S: return launch_one<Env, VEC, A | S>(a, consts, stream);
+    case T: return launch_one<Env, VEC, T>(a, consts, stream);
+    case A | T: return launch_one<Env, VEC, A | T>(a, consts, stream);
+    case A | S | T: return launch_one<Env, VEC, A | S | T>(a, consts, stream);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_step(gymrs_env_kind kind, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
+template <class Env>
+static hipError_t launch_vec(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
+{
+    switch (vec) {
+    case 4: return launch_flags<Env, 4>(flags, a, consts, stream);
+    case 8: return launch_flags<Env, 8>(flags, a, consts, stream);
+    case 16: return launch_flags<Env, 16>(flags, a, consts, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
+                       hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     switch (kind) {
-    case GYMRS_CARTPOLE: return launch_flags<CartPoleT>(flags, a, consts, stream);
-    case GYMRS_MOUNTAIN_CAR: return launch_flags<MountainCarT>(flags, a, consts, stream);
-    case GYMRS_PENDULUM: return launch_flags<PendulumT>(flags, a, consts, stream);
+    case GYMRS_CARTPOLE: return launch_vec<CartPoleT>(vec, flags, a, consts, stream);
+    case GYMRS_MOUNTAIN_CAR: return launch_vec<MountainCarT>(vec, flags, a, consts, stream);
+    case GYMRS_PENDULUM: return launch_vec<PendulumT>(vec, flags, a, consts, stream);
     default: return hipErrorInvalidValue;
     }
 }

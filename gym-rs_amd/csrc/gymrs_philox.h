@@ -53,19 +53,47 @@ GYMRS_HD u32x4 draw4(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t stream
                          (uint32_t)(seed >> 32));
 }
 
-// u32 -> uniform f32 on [low, high): 24 random bits, u*scale + low, guarded to stay below high
-// (half-open like rand's Uniform::new, cartpole.rs:363).
+// u32 -> uniform f32 on [low, high): 24 random bits, u * scale + low, kept below `high` (half-open like
+// rand's Uniform::new, cartpole.rs:363).  Everything that does not depend on the random word is prepared
+// once on the host: v = min(fma(float(r >> 8), scale24, low), high_prev), scale24 = (high - low) * 2^-24,
+// high_prev = the largest float below high.  Three instructions per draw on the GPU.
+struct SampleBox {
+    float lo[4], scale24[4], hi_prev[4];
+};
+
+inline SampleBox make_sample_box(const float* lo, const float* hi, int dims)
+{
+    SampleBox b;
+    for (int j = 0; j < 4; ++j) {
+        b.lo[j] = 0.0f;
+        b.scale24[j] = 0.0f;
+        b.hi_prev[j] = 0.0f;
+    }
+    for (int j = 0; j < dims; ++j) {
+        b.lo[j] = lo[j];
+        b.scale24[j] = (hi[j] - lo[j]) * 0x1p-24f;
+        uint32_t h = f2u(hi[j]);
+        h = (hi[j] > 0.0f) ? h - 1u : ((h & 0x7fffffffu) == 0u ? 0x80000001u : h + 1u);
+        b.hi_prev[j] = u2f(h);
+    }
+    return b;
+}
+
+GYMRS_HD float uniform_in_box(uint32_t r, const SampleBox& b, int j)
+{
+    const float v = fmaf_((float)(r >> 8), b.scale24[j], b.lo[j]);
+    return v < b.hi_prev[j] ? v : b.hi_prev[j]; // v is never NaN: both operands of the min are finite
+}
+
 GYMRS_HD float uniform_between(uint32_t r, float low, float high)
 {
-    float u = (float)(r >> 8) * 0x1p-24f;
-    float v = fmaf_(u, high - low, low);
-    if (!(v < high)) {
-        // largest float below high (high is finite and low < high)
-        uint32_t h = f2u(high);
-        h = (high > 0.0f) ? h - 1u : ((h & 0x7fffffffu) == 0u ? 0x80000001u : h + 1u);
-        v = u2f(h);
-    }
-    return v;
+    SampleBox b;
+    b.lo[0] = low;
+    b.scale24[0] = (high - low) * 0x1p-24f;
+    uint32_t h = f2u(high);
+    h = (high > 0.0f) ? h - 1u : ((h & 0x7fffffffu) == 0u ? 0x80000001u : h + 1u);
+    b.hi_prev[0] = u2f(h);
+    return uniform_in_box(r, b, 0);
 }
 
 } // namespace gymrs

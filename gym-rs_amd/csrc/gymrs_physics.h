@@ -117,13 +117,12 @@ GYMRS_HD float cartpole_reward(bool done, bool& beyond)
 }
 
 // cartpole.rs:317-324: x, x_dot, theta, theta_dot in this order, each on [low, high).
-GYMRS_HD void cartpole_sample(const u32x4& r, const float* lo, const float* hi, float& x, float& x_dot, float& theta,
-                              float& theta_dot)
+GYMRS_HD void cartpole_sample(const u32x4& r, const SampleBox& b, float& x, float& x_dot, float& theta, float& theta_dot)
 {
-    x = uniform_between(r.v[0], lo[0], hi[0]);
-    x_dot = uniform_between(r.v[1], lo[1], hi[1]);
-    theta = uniform_between(r.v[2], lo[2], hi[2]);
-    theta_dot = uniform_between(r.v[3], lo[3], hi[3]);
+    x = uniform_in_box(r.v[0], b, 0);
+    x_dot = uniform_in_box(r.v[1], b, 1);
+    theta = uniform_in_box(r.v[2], b, 2);
+    theta_dot = uniform_in_box(r.v[3], b, 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,9 +165,9 @@ GYMRS_HD bool mountain_car_advance(const MountainCarConsts& c, float& position, 
 }
 
 // mountain_car.rs:162-167: one draw for position, velocity exactly 0.
-GYMRS_HD void mountain_car_sample(const u32x4& r, const float* lo, const float* hi, float& position, float& velocity)
+GYMRS_HD void mountain_car_sample(const u32x4& r, const SampleBox& b, float& position, float& velocity)
 {
-    position = uniform_between(r.v[0], lo[0], hi[0]);
+    position = uniform_in_box(r.v[0], b, 0);
     velocity = 0.0f;
 }
 
@@ -221,10 +220,10 @@ GYMRS_HD float pendulum_advance(const PendulumConsts& c, float& theta, float& th
     return -cost;
 }
 
-GYMRS_HD void pendulum_sample(const u32x4& r, const float* lo, const float* hi, float& theta, float& theta_dot)
+GYMRS_HD void pendulum_sample(const u32x4& r, const SampleBox& b, float& theta, float& theta_dot)
 {
-    theta = uniform_between(r.v[0], lo[0], hi[0]);
-    theta_dot = uniform_between(r.v[1], lo[1], hi[1]);
+    theta = uniform_in_box(r.v[0], b, 0);
+    theta_dot = uniform_in_box(r.v[1], b, 1);
 }
 
 // Default reset boxes (obs_dim lows then highs in the API; here split).

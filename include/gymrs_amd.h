@@ -186,8 +186,8 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
 gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t seed, uint64_t t);
 /* Engine tick (number of reset()/step() calls since the last seeded reset) and current seed. */
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
-/* Kernel geometry knob kept for ABI stability: lanes per work-item is fixed at 4 (one dwordx4 per SoA
- * array); pass 4 or 0, and 0 for `reserved`. */
+/* Kernel geometry knob for tuning/benchmarks: lanes per work-item (4, 8 or 16); `reserved` must be 0.
+ * Results do not depend on it. */
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved);
 
 const char* gymrs_last_error(void);

@@ -217,6 +217,8 @@ class Twin:
         L.twin_philox.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.twin_uniform_between.restype = C.c_float
         L.twin_uniform_between.argtypes = [C.c_uint32, C.c_float, C.c_float]
+        L.twin_uniform_in_box.restype = C.c_float
+        L.twin_uniform_in_box.argtypes = [C.c_uint32, C.c_float, C.c_float]
         L.twin_clipf.restype = C.c_float
         L.twin_clipf.argtypes = [C.c_float] * 3
         L.twin_angle_normalize.restype = C.c_float

@@ -95,12 +95,13 @@ static int state_dim(const twin_engine* e) { return e->kind == GYMRS_CARTPOLE ? 
 static void sample_lane(twin_engine* e, uint64_t i, uint64_t tick)
 {
     const u32x4 r = draw4(e->seed, e->gid0 + i, tick, kStreamReset);
+    const SampleBox b = make_sample_box(e->lo, e->hi, state_dim(e));
     if (e->kind == GYMRS_CARTPOLE) {
-        cartpole_sample(r, e->lo, e->hi, e->s[0][i], e->s[1][i], e->s[2][i], e->s[3][i]);
+        cartpole_sample(r, b, e->s[0][i], e->s[1][i], e->s[2][i], e->s[3][i]);
     } else if (e->kind == GYMRS_MOUNTAIN_CAR) {
-        mountain_car_sample(r, e->lo, e->hi, e->s[0][i], e->s[1][i]);
+        mountain_car_sample(r, b, e->s[0][i], e->s[1][i]);
     } else {
-        pendulum_sample(r, e->lo, e->hi, e->s[0][i], e->s[1][i]);
+        pendulum_sample(r, b, e->s[0][i], e->s[1][i]);
     }
 }
 
@@ -282,6 +283,11 @@ void twin_philox(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
 }
 
 float twin_uniform_between(uint32_t r, float lo, float hi) { return uniform_between(r, lo, hi); }
+float twin_uniform_in_box(uint32_t r, float lo, float hi)
+{
+    const SampleBox b = make_sample_box(&lo, &hi, 1);
+    return uniform_in_box(r, b, 0);
+}
 float twin_clipf(float v, float l, float r) { return clipf(v, l, r); }
 float twin_angle_normalize(float x) { return angle_normalize(x); }
 

@@ -36,11 +36,11 @@ def random_states(kind, n, rng):
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])
-@pytest.mark.parametrize("n", [100_003, 1, 1023, 4096])  # ragged tails, a single lane, exact tiles
-def test_single_step_vs_f64_oracle(kind, n, gymrs, oracle):
+@pytest.mark.parametrize("n,vec", [(100_003, 4), (1, 4), (1023, 8), (4096, 16), (70_001, 16)])  # ragged tails, one lane, exact tiles
+def test_single_step_vs_f64_oracle(kind, n, vec, gymrs, oracle):
     rng = np.random.default_rng(100 + kind)
     st, act = random_states(kind, n, rng)
-    with gymrs.BatchedEngine(kind, n, flags=0) as eng:
+    with gymrs.BatchedEngine(kind, n, flags=0, lanes_per_thread=vec) as eng:
         eng.reset(seed=1)
         eng.set_state(st)
         eng.step_host(act)
@@ -91,8 +91,8 @@ def test_multistep_bit_exact_vs_f32_twin(kind, flagset, gymrs, twin):
     params = gymrs.engine.default_params(kind)
     if flags & gymrs.TIME_LIMIT:
         params.max_episode_steps = 17
-    for n in (20_011, 2048):
-        eng = gymrs.BatchedEngine(kind, n, flags=flags, params=params, global_env_offset=12345)
+    for n, vec in ((20_011, 4), (2048, 8), (9_999, 16)):
+        eng = gymrs.BatchedEngine(kind, n, flags=flags, params=params, global_env_offset=12345, lanes_per_thread=vec)
         tw = TwinEngine(twin, kind, n, params, flags=flags, gid0=12345)
         eng.reset(seed=2024)
         tw.reset(2024)

@@ -38,8 +38,14 @@ def test_uniform_between_half_open(twin):
     top = f(0xFFFFFFFF, -0.05, 0.05)
     assert top < np.float32(0.05) and top > 0.0499
     assert f(0xFFFFFFFF, -0.6, -0.4) < np.float32(-0.4)
-    assert f(0xFFFFFFFF, 0.0, 1e-38) < np.float32(1e-38)  # the guard keeps the result below `high`
+    assert f(0xFFFFFFFF, 0.0, 1e-38) < np.float32(1e-38)  # the result always stays below `high`
     assert f(0x80000000, 0.0, 2.0) == 1.0
+    # the host-prepared form the kernels use (3 instructions per draw) is bit-identical
+    g = twin.lib.twin_uniform_in_box
+    rng = np.random.default_rng(3)
+    for lo, hi in ((-0.05, 0.05), (-0.6, -0.4), (-3.1415927, 3.1415927), (0.0, 1e-38), (-1.0, 0.0), (5.0, 6.0), (-2.0, 2.0)):
+        for r in [0, 1, 0xFF, 0x100, 0x7FFFFFFF, 0x80000000, 0xFFFFFF00, 0xFFFFFFFF] + [int(v) for v in rng.integers(0, 2**32, 200)]:
+            assert g(r, lo, hi) == f(r, lo, hi), (r, lo, hi)
 
 
 @pytest.mark.parametrize("kind", [0, 1, 2])

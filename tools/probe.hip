@@ -145,10 +145,10 @@ int main(int argc, char** argv)
     struct Cfg { int kind; uint32_t flags; int vec, tiles, prio; };
     std::vector<Cfg> cfgs;
     const uint32_t AS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS;
-    for (int vec : {4}) for (int tiles : {1}) for (int prio : {0}) {
+    for (int vec : {4, 8, 16}) for (int tiles : {1}) for (int prio : {0}) {
         cfgs.push_back({0, AS, vec, tiles, prio});
     }
-    for (int vec : {4}) for (int tiles : {1}) { cfgs.push_back({0, 0u, vec, tiles, 0}); cfgs.push_back({0, GYMRS_AUTO_RESET, vec, tiles, 0}); cfgs.push_back({1, AS, vec, tiles, 0}); cfgs.push_back({2, AS | GYMRS_TIME_LIMIT, vec, tiles, 0}); }
+    for (int vec : {4, 8, 16}) for (int tiles : {1}) { cfgs.push_back({0, 0u, vec, tiles, 0}); cfgs.push_back({0, GYMRS_AUTO_RESET, vec, tiles, 0}); cfgs.push_back({1, AS, vec, tiles, 0}); cfgs.push_back({2, AS | GYMRS_TIME_LIMIT, vec, tiles, 0}); }
     for (const Cfg& cf : cfgs) {
         const int kind = cf.kind;
         const size_t asz = kind == 2 ? 4 : 1;
@@ -180,7 +180,7 @@ int main(int argc, char** argv)
         printf("%-50s %8.2f us/launch\n", name, us);
     }
     // lane-partitioned chains on separate streams, eager and as a captured HIP graph
-    for (int parts : {1, 2}) for (int graph : {0, 1}) for (int vec : {4}) {
+    for (int parts : {1}) for (int graph : {0}) for (int vec : {4}) {
         std::vector<gymrs_engine*> es(parts); std::vector<hipStream_t> ss(parts);
         size_t np = n / parts;
         for (int p = 0; p < parts; ++p) {

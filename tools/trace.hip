@@ -1,0 +1,45 @@
+// tools/trace.hip — developer tool: per-wave phase timeline of step_kernel (needs a GYMRS_TRACE_TIMES build).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#include "gymrs_amd.h"
+extern "C" gymrs_status gymrs_dev_set_trace(gymrs_engine* e, unsigned long long* buf);
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv)
+{
+    const size_t n = 1u << 20;
+    const uint32_t flags = argc > 1 ? atoi(argv[1]) : 3;
+    gymrs_engine* e;
+    if (gymrs_engine_create(GYMRS_CARTPOLE, n, 0, 0, nullptr, flags, &e)) { printf("%s\n", gymrs_last_error()); return 1; }
+    unsigned char* act; CK(hipMalloc(&act, n * 8));
+    for (int b = 0; b < 8; ++b) gymrs_fill_actions(e, act + (size_t)b * n, 1, b);
+    gymrs_reset(e, 1, 0, nullptr, nullptr);
+    gymrs_step_many(e, act, n, 8, 200, 0);
+    gymrs_sync(e);
+    const size_t waves = n / 256;
+    unsigned long long* tr; CK(hipMalloc(&tr, waves * 8 * 8)); CK(hipMemset(tr, 0, waves * 8 * 8));
+    gymrs_dev_set_trace(e, tr);
+    gymrs_step_many(e, act, n, 8, 3, 0);
+    gymrs_sync(e);
+    std::vector<unsigned long long> h(waves * 8);
+    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t w = 0; w < waves; ++w) t0 = std::min(t0, h[w * 8]);
+    const char* names[7] = {"start", "loads issued", "loads landed", "physics done", "reset done", "stores issued", "end (stores acked)"};
+    printf("per-wave s_memtime stamps relative to the earliest wave start (ticks; 100 MHz constant clock => 10 ns/tick)\n");
+    for (int s = 0; s < 7; ++s) {
+        std::vector<long long> v(waves);
+        for (size_t w = 0; w < waves; ++w) v[w] = (long long)(h[w * 8 + s] - t0);
+        std::sort(v.begin(), v.end());
+        printf("%-20s min %6lld  p10 %6lld  median %6lld  p90 %6lld  max %6lld\n", names[s], v[0], v[waves / 10], v[waves / 2], v[waves * 9 / 10], v[waves - 1]);
+    }
+    const char* dn[6] = {"issue loads", "wait for loads", "physics", "auto-reset", "issue stores", "store ack"};
+    for (int s = 0; s < 6; ++s) {
+        std::vector<long long> v(waves);
+        for (size_t w = 0; w < waves; ++w) v[w] = (long long)(h[w * 8 + s + 1] - h[w * 8 + s]);
+        std::sort(v.begin(), v.end());
+        printf("phase %-16s min %6lld  median %6lld  p90 %6lld  max %6lld\n", dn[s], v[0], v[waves / 2], v[waves * 9 / 10], v[waves - 1]);
+    }
+    return 0;
+}
