@@ -68,6 +68,7 @@ def main() -> int:
     ap.add_argument("--env", choices=sorted(ENVS), default="cartpole")
     ap.add_argument("--n-envs", type=int, default=0, help="lanes per GPU (default: the BASELINE config)")
     ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4, 8, 16); 0 = engine default")
+    ap.add_argument("--nt", type=int, default=0, help="memory hint: 0 auto, 1 always non-temporal, 2 never")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
@@ -88,7 +89,9 @@ def main() -> int:
         print("bench.py: no GPU visible; the stepper has no CPU fallback", file=sys.stderr)
         return 2
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = os.environ.get("GYMRS_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
+    dist_on = world > 1 or (force_dist and "RANK" in os.environ)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -100,6 +103,8 @@ def main() -> int:
         flags |= gymrs.TIME_LIMIT  # it never terminates; episodes end by the 200-step limit only
     eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags,
                               lanes_per_thread=args.vec or None)
+    if args.nt:
+        eng.set_tuning(args.vec or 4, args.nt)
     stream = torch.cuda.ExternalStream(eng.stream, device=local_rank)
 
     # synthetic inputs, resident in HBM before the timed region
@@ -114,21 +119,27 @@ def main() -> int:
     eng.step_many(actions.data_ptr(), stride, nbuf, args.warmup)
     eng.sync()
     eng.stats_clear()
-    if args.native_rccl and world > 1:
+    if args.native_rccl and dist_on:
         uid = [eng.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         eng.comm_init(world, rank, uid[0])
 
+    if dist_on and not args.native_rccl:
+        # RCCL builds its communicator lazily on the first collective: do one outside the timed region
+        dist.all_reduce(torch.zeros(4, dtype=torch.float64, device=f"cuda:{local_rank}"))
+    elif dist_on:
+        eng.allreduce_stats()
+
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
     eng.step_many(actions.data_ptr(), stride, nbuf, args.steps)
     ev1.record(stream)
-    if world > 1:
+    if dist_on:
         if args.native_rccl:
             total = eng.allreduce_stats()
         else:
@@ -139,13 +150,13 @@ def main() -> int:
         total = eng.stats()
     eng.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t1 = time.perf_counter()
 
     wall = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the engine's stream around the K launches
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, kernel_ms = float(tmax[0]), float(tmax[1])
@@ -206,7 +217,7 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
     return 0
 

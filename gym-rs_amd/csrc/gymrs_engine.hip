@@ -77,7 +77,9 @@ struct gymrs_engine {
     float* ep_ret = nullptr;
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
+    void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
     int vec = 4; // lanes per work-item
+    int nt_mode = 0; // 0 = automatic, 1 = always non-temporal, 2 = never
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
     double* stats_dev = nullptr;
@@ -109,6 +111,17 @@ static uint64_t os_entropy()
     // seeding.rs:22 `thread_rng().gen()`: a fresh seed from the OS
     std::random_device rd;
     return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
+}
+
+// Non-temporal accesses pay off while one step's arrays (state in + out, rewards, flags) are small next to
+// the 256 MB Infinity Cache; beyond that the cache serving the next step's reads is worth more (measured:
+// CartPole 2^20 lanes 7.2 vs 7.5 us, 2^22 lanes 30 vs 26 us).  Threshold: 48 MiB of per-step traffic.
+static uint32_t launch_flags_of(const gymrs_engine* e)
+{
+    const uint64_t bytes_per_lane = (uint64_t)e->state_dim * 8 + 10 + (e->kind == GYMRS_PENDULUM ? 8 : 0);
+    const bool small = e->n * bytes_per_lane <= (48ull << 20);
+    const bool nt = e->nt_mode == 1 || (e->nt_mode == 0 && small);
+    return e->flags | (nt ? kFlagNonTemporal : 0u);
 }
 
 static StepArgs step_args(const gymrs_engine* e, const void* actions)
@@ -288,15 +301,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    for (int j = 0; j < 4; ++j) (void)hipFree(e->s[j]);
-    (void)hipFree(e->obs_cos);
-    (void)hipFree(e->obs_sin);
-    (void)hipFree(e->reward);
-    (void)hipFree(e->done);
-    (void)hipFree(e->truncated);
-    (void)hipFree(e->beyond);
-    (void)hipFree(e->ep_start);
-    (void)hipFree(e->ep_ret);
+    (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
     (void)hipFree(e->err);
     (void)hipFree(e->stats_dev);
@@ -385,17 +390,51 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     // Arrays are padded to a multiple of 16 lanes so the last vector access of the engine's own
     // arrays stays inside the allocation; the caller's action buffer is never read past n.
     const size_t npad = (size_t)((n_envs + 15) & ~15ull);
-    for (int j = 0; j < e->state_dim; ++j) chk(dev_alloc(&e->s[j], npad));
-    if (kind == GYMRS_PENDULUM) {
-        chk(dev_alloc(&e->obs_cos, npad));
-        chk(dev_alloc(&e->obs_sin, npad));
-        if (flags & GYMRS_TRACK_STATS) chk(dev_alloc(&e->ep_ret, npad));
+    // All per-lane arrays live in ONE allocation, each array start skewed by a different odd multiple of
+    // `skew` bytes.  With separate power-of-two sized allocations (2^20 lanes = exactly 4 MiB per f32 array)
+    // lane i of every array maps to the same memory channel / cache set and a wave's 5 loads and 6 stores
+    // pile onto it (measured: 7.7 us per launch at 2^20 lanes against 7.1 us per 2^20 at 1.5 * 2^20).
+    {
+        size_t skew = 4352; // 4 KiB + 256 B
+        if (const char* env = std::getenv("GYMRS_ARRAY_SKEW")) skew = (size_t)std::strtoull(env, nullptr, 10) & ~(size_t)255;
+        size_t off = 0;
+        int index = 0;
+        auto place = [&](size_t bytes) {
+            const size_t at = off + (size_t)index * skew;
+            ++index;
+            off = (at + bytes + 255) & ~(size_t)255;
+            return at;
+        };
+        size_t at_s[4] = {0, 0, 0, 0}, at_cos = 0, at_sin = 0, at_ret = 0;
+        for (int j = 0; j < e->state_dim; ++j) at_s[j] = place(npad * 4);
+        const bool pend = kind == GYMRS_PENDULUM;
+        if (pend) {
+            at_cos = place(npad * 4);
+            at_sin = place(npad * 4);
+            if (flags & GYMRS_TRACK_STATS) at_ret = place(npad * 4);
+        }
+        const size_t at_reward = place(npad * 4), at_done = place(npad), at_trunc = place(npad), at_beyond = place(npad),
+                     at_start = place(npad * 4);
+        void* pool = nullptr;
+        hipError_t perr = hipMalloc(&pool, off + 256);
+        if (perr != hipSuccess) {
+            delete e;
+            return fail(perr == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("hipMalloc: ") + hipGetErrorString(perr));
+        }
+        e->pool = pool;
+        char* b = static_cast<char*>(pool);
+        for (int j = 0; j < e->state_dim; ++j) e->s[j] = reinterpret_cast<float*>(b + at_s[j]);
+        if (pend) {
+            e->obs_cos = reinterpret_cast<float*>(b + at_cos);
+            e->obs_sin = reinterpret_cast<float*>(b + at_sin);
+            if (flags & GYMRS_TRACK_STATS) e->ep_ret = reinterpret_cast<float*>(b + at_ret);
+        }
+        e->reward = reinterpret_cast<float*>(b + at_reward);
+        e->done = reinterpret_cast<uint8_t*>(b + at_done);
+        e->truncated = reinterpret_cast<uint8_t*>(b + at_trunc);
+        e->beyond = reinterpret_cast<uint8_t*>(b + at_beyond);
+        e->ep_start = reinterpret_cast<uint32_t*>(b + at_start);
     }
-    chk(dev_alloc(&e->reward, npad));
-    chk(dev_alloc(&e->done, npad));
-    chk(dev_alloc(&e->truncated, npad));
-    chk(dev_alloc(&e->beyond, npad));
-    chk(dev_alloc(&e->ep_start, npad));
     e->n_stat_blocks = step_grid(n_envs, 4) * (kBlock / 64); // one statistics slot per wavefront (most waves at vec = 4)
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->err, 2));
@@ -451,13 +490,14 @@ gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream)
     return GYMRS_OK;
 }
 
-gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved)
+gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
     if (lanes_per_thread != 4 && lanes_per_thread != 8 && lanes_per_thread != 16)
         return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4, 8 or 16");
-    if (reserved != 0) return fail(GYMRS_EINVAL, "gymrs_set_tuning: reserved must be 0");
+    if (memory_hint < 0 || memory_hint > 2) return fail(GYMRS_EINVAL, "gymrs_set_tuning: memory_hint must be 0, 1 or 2");
     e->vec = lanes_per_thread;
+    e->nt_mode = memory_hint;
     return GYMRS_OK;
 }
 
@@ -519,7 +559,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     StepArgs a = step_args(e, actions_dev);
-    HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
+    HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
     e->tick += 1;
     e->n_steps_total += (double)e->n;
     return GYMRS_OK;
@@ -545,7 +585,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     const char* base = static_cast<const char*>(actions_dev);
     for (uint32_t t = 0; t < n_steps; ++t) {
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
-        HIP_TRY(launch_step(e->kind, e->vec, e->flags, a, consts_ptr(e), e->stream));
+        HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
         e->tick += 1;
     }
     e->n_steps_total += (double)e->n * (double)n_steps;

@@ -8,6 +8,7 @@
 namespace gymrs {
 
 constexpr int kBlock = 256; // 4 wavefronts of 64
+constexpr uint32_t kFlagNonTemporal = 0x100u; // internal launch flag (not an engine flag): non-temporal loads/stores
 
 // Everything one step() launch needs.  Device pointers are SoA arrays of n lanes.
 struct StepArgs {

@@ -55,12 +55,20 @@ struct alignas(sizeof(T) * V) Vec {
     T v[V];
 };
 
-template <class T, int V>
+// NT = the accesses carry the non-temporal hint.  Every array is read once and written once per step and
+// the next reader is the NEXT kernel (a kernel boundary flushes/invalidates the per-XCD L2s anyway), so
+// nothing is gained by keeping the lines in L2: measured -0.4 us per 2^20-lane launch.  The hint also keeps
+// the lines out of the 256 MB Infinity Cache, which is what serves the next step's reads while the working
+// set fits there, so above ~2^20 CartPole lanes plain accesses win again; the engine picks per launch.
+template <class T, int V, bool NT>
 __device__ __forceinline__ Vec<T, V> load_vec(const T* __restrict__ p, uint64_t base, uint64_t n, bool full, T fill)
 {
+    typedef T vt __attribute__((ext_vector_type(V)));
     Vec<T, V> r;
     if (full) {
-        r = *reinterpret_cast<const Vec<T, V>*>(p + base);
+        const vt x = NT ? __builtin_nontemporal_load(reinterpret_cast<const vt*>(p + base)) : *reinterpret_cast<const vt*>(p + base);
+#pragma unroll
+        for (int k = 0; k < V; ++k) r.v[k] = x[k];
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k) r.v[k] = (base + k < n) ? p[base + k] : fill;
@@ -68,11 +76,18 @@ __device__ __forceinline__ Vec<T, V> load_vec(const T* __restrict__ p, uint64_t 
     return r;
 }
 
-template <class T, int V>
+template <class T, int V, bool NT>
 __device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint64_t n, bool full, const Vec<T, V>& r)
 {
+    typedef T vt __attribute__((ext_vector_type(V)));
     if (full) {
-        *reinterpret_cast<Vec<T, V>*>(p + base) = r;
+        vt x;
+#pragma unroll
+        for (int k = 0; k < V; ++k) x[k] = r.v[k];
+        if (NT)
+            __builtin_nontemporal_store(x, reinterpret_cast<vt*>(p + base));
+        else
+            *reinterpret_cast<vt*>(p + base) = x;
     } else {
 #pragma unroll
         for (int k = 0; k < V; ++k)
@@ -166,6 +181,7 @@ struct TileRegs {
     static constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     static constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
     static constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
+    static constexpr bool NT = (FLAGS & kFlagNonTemporal) != 0;
     Vec<float, VEC> st[Env::kState];
     Vec<typename Env::Action, VEC> act;
     Vec<uint8_t, VEC> beyond;
@@ -180,11 +196,11 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
     using R = TileRegs<Env, VEC, FLAGS>;
     using Action = typename Env::Action;
 #pragma unroll
-    for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec>(a.s[j], base, a.n, FULL, 0.0f);
-    d.act = load_vec<Action, kVec>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
-    if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec>(a.beyond, base, a.n, FULL, uint8_t(0));
-    if (R::TLIM) d.ep_start = load_vec<uint32_t, kVec>(a.ep_start, base, a.n, FULL, 0u);
-    if (R::STATS && !Env::kConstReward) d.ep_ret = load_vec<float, kVec>(a.ep_ret, base, a.n, FULL, 0.0f);
+    for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, 0.0f);
+    d.act = load_vec<Action, kVec, R::NT>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
+    if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, uint8_t(0));
+    if (R::TLIM) d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
+    if (R::STATS && !Env::kConstReward) d.ep_ret = load_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, 0.0f);
 }
 
 // LDS of one workgroup for the auto-reset hand-off: every wavefront uses its own 256-entry segment
@@ -342,7 +358,13 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
 #pragma unroll
                 for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
                 lds.fresh[wave * LPW + i] = fs;
+#ifndef GYMRS_EXP_NO_EPSTORE
+#ifdef GYMRS_EXP_NT_EPSTORE
+                if (STATS || TLIM) __builtin_nontemporal_store(tick_next, a.ep_start + gl);
+#else
                 if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick
+#endif
+#endif
                 if (STATS && !Env::kConstReward) ret_sum += lds.ret[wave * LPW + i]; // return of the finished episode
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -363,7 +385,9 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
                     for (int off = 32; off > 0; off >>= 1) ret_sum += __shfl_xor(ret_sum, off);
                     if (lane == 0) reinterpret_cast<double*>(bs)[1] = old_ret + (double)ret_sum;
                 }
+#ifndef GYMRS_EXP_NO_SLOT
                 if (lane == 0) bs[0] = old_resets + total;
+#endif
             }
         }
     }
@@ -378,13 +402,13 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
         Vec<float, kVec> out;
 #pragma unroll
         for (int k = 0; k < kVec; ++k) out.v[k] = ls[j][k];
-        store_vec<float, kVec>(a.s[j], base, a.n, FULL, out);
+        store_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, out);
     }
-    store_vec<float, kVec>(a.reward, base, a.n, FULL, reward);
-    store_vec<uint8_t, kVec>(a.done, base, a.n, FULL, done);
-    if (TLIM) store_vec<uint8_t, kVec>(a.truncated, base, a.n, FULL, trunc);
-    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec>(a.beyond, base, a.n, FULL, d.beyond);
-    if (STATS && !Env::kConstReward) store_vec<float, kVec>(a.ep_ret, base, a.n, FULL, d.ep_ret);
+    store_vec<float, kVec, R::NT>(a.reward, base, a.n, FULL, reward);
+    store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, done);
+    if (TLIM) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, trunc);
+    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, d.beyond);
+    if (STATS && !Env::kConstReward) store_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, d.ep_ret);
     if (Env::kHasObsExtra) {
         Vec<float, kVec> oc, os;
         bool med = true;
@@ -397,8 +421,8 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
 #pragma unroll
             for (int k = 0; k < kVec; ++k) sincosf_(ls[0][k], &os.v[k], &oc.v[k]);
         }
-        store_vec<float, kVec>(a.obs_cos, base, a.n, FULL, oc);
-        store_vec<float, kVec>(a.obs_sin, base, a.n, FULL, os);
+        store_vec<float, kVec, R::NT>(a.obs_cos, base, a.n, FULL, oc);
+        store_vec<float, kVec, R::NT>(a.obs_sin, base, a.n, FULL, os);
     }
     GYMRS_STAMP(5); // stores issued
 #ifdef GYMRS_TRACE_TIMES
@@ -414,8 +438,12 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
     const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * kVec;
+    GYMRS_STAMP(0);
+    TileRegs<Env, VEC, FLAGS> d;
+    load_tile<Env, VEC, FLAGS, FULL>(a, base, d);
     // Episode statistics: every wavefront owns one {finished episodes, sum of returns} slot.  The old value
-    // is fetched with the first loads and the updated value leaves with the wave's last stores, so the hot
+    // is fetched right behind the state loads (after them, so that the slot pointer does not split the
+    // kernel-argument fetch in two) and the updated value leaves with the wave's last stores: the hot
     // path holds no atomic and nothing waits on the statistics.  (Launches are stream-ordered and a slot
     // has exactly one writer per launch.)
     unsigned long long old_resets = 0;
@@ -425,9 +453,6 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
         old_resets = bs[0];
         if (!Env::kConstReward) old_ret = reinterpret_cast<const double*>(bs)[1];
     }
-    GYMRS_STAMP(0);
-    TileRegs<Env, VEC, FLAGS> d;
-    load_tile<Env, VEC, FLAGS, FULL>(a, base, d);
     GYMRS_STAMP(1);
     finish_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret);
     GYMRS_STAMP(6);
@@ -560,20 +585,27 @@ static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t 
     return hipGetLastError();
 }
 
-template <class Env, int VEC>
-static hipError_t launch_flags(uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
+template <class Env, int VEC, uint32_t NTBIT>
+static hipError_t launch_flags_nt(uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
 {
     constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
     if (!(flags & A)) flags &= ~S; // statistics need auto-reset
     switch (flags & (A | S | T)) {
-    case 0: return launch_one<Env, VEC, 0>(a, consts, stream);
-    case A: return launch_one<Env, VEC, A>(a, consts, stream);
-    case A | S: return launch_one<Env, VEC, A | S>(a, consts, stream);
-    case T: return launch_one<Env, VEC, T>(a, consts, stream);
-    case A | T: return launch_one<Env, VEC, A | T>(a, consts, stream);
-    case A | S | T: return launch_one<Env, VEC, A | S | T>(a, consts, stream);
+    case 0: return launch_one<Env, VEC, 0 | NTBIT>(a, consts, stream);
+    case A: return launch_one<Env, VEC, A | NTBIT>(a, consts, stream);
+    case A | S: return launch_one<Env, VEC, A | S | NTBIT>(a, consts, stream);
+    case T: return launch_one<Env, VEC, T | NTBIT>(a, consts, stream);
+    case A | T: return launch_one<Env, VEC, A | T | NTBIT>(a, consts, stream);
+    case A | S | T: return launch_one<Env, VEC, A | S | T | NTBIT>(a, consts, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+template <class Env, int VEC>
+static hipError_t launch_flags(uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
+{
+    return (flags & kFlagNonTemporal) ? launch_flags_nt<Env, VEC, kFlagNonTemporal>(flags, a, consts, stream)
+                                      : launch_flags_nt<Env, VEC, 0u>(flags, a, consts, stream);
 }
 
 template <class Env>

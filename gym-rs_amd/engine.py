@@ -141,8 +141,9 @@ class BatchedEngine:
     def set_stream(self, hip_stream: int) -> None:
         _check(self._lib, self._lib.gymrs_set_stream(self._h, C.c_void_p(hip_stream)))
 
-    def set_tuning(self, lanes_per_thread: int = 4) -> None:
-        _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), 0))
+    def set_tuning(self, lanes_per_thread: int = 4, memory_hint: int = 0) -> None:
+        """memory_hint: 0 automatic, 1 always non-temporal accesses, 2 never."""
+        _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), int(memory_hint)))
 
     # -- Env::reset ------------------------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, options: Optional[Sequence[float]] = None) -> int:

@@ -186,9 +186,10 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
 gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t seed, uint64_t t);
 /* Engine tick (number of reset()/step() calls since the last seeded reset) and current seed. */
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
-/* Kernel geometry knob for tuning/benchmarks: lanes per work-item (4, 8 or 16); `reserved` must be 0.
- * Results do not depend on it. */
-gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int reserved);
+/* Kernel tuning knobs for benchmarks; results never depend on them.  lanes_per_thread: 4 (default), 8 or
+ * 16 lanes per work-item.  memory_hint: 0 = automatic (non-temporal loads/stores while one step's traffic is
+ * <= 48 MiB), 1 = always non-temporal, 2 = never. */
+gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint);
 
 const char* gymrs_last_error(void);
 int gymrs_abi_version(void);

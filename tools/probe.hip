@@ -34,6 +34,38 @@ __global__ __launch_bounds__(256) void copy_tile(float* s0, float* s1, float* s2
     *(F<V>*)(rew + i) = r; *(B<V>*)(done + i) = dn;
 }
 
+// copy_tile with non-temporal stores / loads (does the end-of-kernel write-back get cheaper?)
+template <int V, int MODE>
+__global__ __launch_bounds__(256) void copy_tile_nt(float* s0, float* s1, float* s2, float* s3, const unsigned char* act,
+                                                    float* rew, unsigned char* done, size_t n)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 4 > n) return;
+    f4 a, b, c, d;
+    if (MODE & 2) {
+        a = __builtin_nontemporal_load((f4*)(s0 + i)); b = __builtin_nontemporal_load((f4*)(s1 + i));
+        c = __builtin_nontemporal_load((f4*)(s2 + i)); d = __builtin_nontemporal_load((f4*)(s3 + i));
+    } else {
+        a = *(f4*)(s0 + i); b = *(f4*)(s1 + i); c = *(f4*)(s2 + i); d = *(f4*)(s3 + i);
+    }
+    unsigned u = *(const unsigned*)(act + i);
+    f4 r = {1.f, 1.f, 1.f, 1.f};
+    unsigned dn = 0;
+    for (int k = 0; k < 4; ++k) {
+        float f = ((u >> (8 * k)) & 0xff) ? 1.0f : -1.0f;
+        a[k] += 0.02f * b[k]; b[k] += 0.02f * f; c[k] += 0.02f * d[k]; d[k] -= 0.02f * f;
+        dn |= (a[k] > 2.4f ? 1u : 0u) << (8 * k);
+    }
+    if (MODE & 1) {
+        __builtin_nontemporal_store(a, (f4*)(s0 + i)); __builtin_nontemporal_store(b, (f4*)(s1 + i));
+        __builtin_nontemporal_store(c, (f4*)(s2 + i)); __builtin_nontemporal_store(d, (f4*)(s3 + i));
+        __builtin_nontemporal_store(r, (f4*)(rew + i)); __builtin_nontemporal_store(dn, (unsigned*)(done + i));
+    } else {
+        *(f4*)(s0 + i) = a; *(f4*)(s1 + i) = b; *(f4*)(s2 + i) = c; *(f4*)(s3 + i) = d; *(f4*)(rew + i) = r; *(unsigned*)(done + i) = dn;
+    }
+}
+
 // copy_tile + K rounds of arithmetic per work-item between the loads and the stores: calibrates what one
 // VALU instruction per wave costs in this launch shape.  MODE 0: 4 independent scalar FMA chains
 // (one per lane of the work-item), MODE 1: the same as 2 packed chains.
@@ -139,6 +171,8 @@ int main(int argc, char** argv)
 #define PERS(V, G) report("copy_persist V=" #V " grid=" #G, time_launches(st, iters, [&] { hipLaunchKernelGGL(copy_persist<V>, dim3(G), dim3(256), 0, st, s[0], s[1], s[2], s[3], act, rew, done, n); }))
     PERS(1, 512); PERS(1, 1024); PERS(1, 2048); PERS(2, 512); PERS(2, 1024); PERS(4, 256); PERS(4, 512);
 
+#define NT(M) report("copy_tile_nt mode=" #M " (1=nt stores, 2=nt loads)", time_launches(st, iters, [&] { hipLaunchKernelGGL((copy_tile_nt<4, M>), dim3((n + 1023) / 1024), dim3(256), 0, st, s[0], s[1], s[2], s[3], act, rew, done, n); }))
+    NT(0); NT(1); NT(2); NT(3);
 #define ALU(K, M) report("copy_alu V=4 K=" #K " mode=" #M, time_launches(st, iters, [&] { hipLaunchKernelGGL((copy_alu<K, M>), dim3((n + 1023) / 1024), dim3(256), 0, st, s[0], s[1], s[2], s[3], act, rew, done, n, 0.999f, 1e-3f); }))
     ALU(0, 0); ALU(25, 0); ALU(50, 0); ALU(100, 0); ALU(200, 0); ALU(400, 0); ALU(25, 1); ALU(50, 1); ALU(100, 1); ALU(200, 1); ALU(400, 1);
     // the engine's kernels through the C ABI
