@@ -358,13 +358,8 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
 #pragma unroll
                 for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
                 lds.fresh[wave * LPW + i] = fs;
-#ifndef GYMRS_EXP_NO_EPSTORE
-#ifdef GYMRS_EXP_NT_EPSTORE
-                if (STATS || TLIM) __builtin_nontemporal_store(tick_next, a.ep_start + gl);
-#else
-                if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick
-#endif
-#endif
+                if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick (plain store:
+                                                               // a non-temporal scattered dword store measured slower)
                 if (STATS && !Env::kConstReward) ret_sum += lds.ret[wave * LPW + i]; // return of the finished episode
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -385,9 +380,7 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
                     for (int off = 32; off > 0; off >>= 1) ret_sum += __shfl_xor(ret_sum, off);
                     if (lane == 0) reinterpret_cast<double*>(bs)[1] = old_ret + (double)ret_sum;
                 }
-#ifndef GYMRS_EXP_NO_SLOT
                 if (lane == 0) bs[0] = old_resets + total;
-#endif
             }
         }
     }
