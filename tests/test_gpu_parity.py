@@ -380,3 +380,60 @@ def test_reset_distribution_on_gpu(gymrs):
         eng.reset(seed=7)
         s = eng.get_state().astype(np.float64)
         assert stats.kstest(s[0], "uniform", args=(-0.6, 0.2)).pvalue > 1e-4 and (s[1] == 0).all()
+
+
+def test_custom_physics_params_and_semi_implicit_integrator(gymrs, oracle, twin, golden):
+    """The reference's physics constants are mutable `pub` fields (cartpole.rs:53-82) and
+    KinematicsIntegrator::Other switches to semi-implicit Euler (cartpole.rs:436-441): both must reach the
+    kernel (as kernel arguments), match the f64 oracle with the same parameters and stay bit-exact vs the twin."""
+    n = 50_000
+    rng = np.random.default_rng(77)
+    st, act = random_states(0, n, rng)
+    for integrator, tweak in ((1, {}), (0, {"gravity": 3.7, "masspole": 0.25, "length": 0.8, "force_mag": 7.5, "tau": 0.01}),
+                              (1, {"masscart": 2.0, "x_threshold": 1.0, "theta_threshold_radians": 0.1})):
+        p = gymrs.engine.default_params(0)
+        op = oracle.cartpole_params()
+        p.kinematics_integrator = integrator
+        op.kinematics_integrator = integrator
+        for k, v in tweak.items():
+            setattr(p, k, v)
+            setattr(op, k, v)
+        with gymrs.BatchedEngine(0, n, flags=0, params=p) as eng:
+            eng.reset(seed=1)
+            eng.set_state(st)
+            eng.step_host(act)
+            got = eng.get_state()
+            _, done, _ = eng.get_step_result()
+        ref = st.astype(np.float64).copy()
+        _, ref_d, _ = oracle.cartpole_step_batch(ref, np.zeros(n, np.uint8), act, op)
+        assert mixed_err(got, ref).max() <= TOL, (integrator, tweak)
+        near = (np.abs(np.abs(ref[0]) - op.x_threshold) < 1e-5) | (np.abs(np.abs(ref[2]) - op.theta_threshold_radians) < 1e-5)
+        assert near[done != ref_d].all()
+        tw = TwinEngine(twin, 0, n, p, flags=0)
+        tw.reset(1)
+        tw.set_state(st)
+        tw.step(act)
+        assert np.array_equal(got.view(np.uint32), tw.get_state().view(np.uint32))
+    # the committed semi-implicit golden vectors
+    cases = golden("cartpole")["semi_implicit"]
+    p = gymrs.engine.default_params(0)
+    p.kinematics_integrator = 1
+    with gymrs.BatchedEngine(0, len(cases), params=p) as eng:
+        eng.set_state(np.array([c["state"] for c in cases], np.float32).T)
+        eng.step_host(np.array([c["action"] for c in cases], np.uint8))
+        got = eng.get_state()
+    assert mixed_err(got, np.array([c["next"] for c in cases]).T).max() <= 2e-6
+    # MountainCar with other constants
+    pm = gymrs.engine.default_params(1)
+    om = oracle.mountain_car_params()
+    for k, v in {"force": 0.002, "gravity": 0.003, "max_speed": 0.05, "goal_position": 0.45}.items():
+        setattr(pm, k, v)
+        setattr(om, k, v)
+    st, act = random_states(1, n, rng)
+    with gymrs.BatchedEngine(1, n, params=pm) as eng:
+        eng.set_state(st)
+        eng.step_host(act)
+        got = eng.get_state()
+    ref = st.astype(np.float64).copy()
+    oracle.mountain_car_step_batch(ref, act, om)
+    assert mixed_err(got, ref).max() <= TOL
