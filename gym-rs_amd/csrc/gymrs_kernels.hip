@@ -136,13 +136,13 @@ struct MountainCarT {
         done = mountain_car_advance(c, st[0], st[1], a);
         reward = -1.0f;
     }
-    __device__ static bool fast_ok(const float* st, Action a) { return a < 3 && in_medium_range(3.0f * st[0]); }
+    __device__ static bool fast_ok(const float* st, Action a) { return a < 3 && in_short_range(3.0f * st[0]); }
     static constexpr int kVariants = 1;
     __device__ static int variant(const Consts&) { return 0; }
     template <int>
     __device__ static void advance_fast(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
-        done = mountain_car_advance<SinCosMedium>(c, st[0], st[1], a);
+        done = mountain_car_advance<SinCosShort>(c, st[0], st[1], a);
         reward = -1.0f;
     }
     __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { mountain_car_sample(r, b, st[0], st[1]); }
@@ -161,14 +161,13 @@ struct PendulumT { // spec-derived, not in the reference
         reward = pendulum_advance(c, st[0], st[1], a);
         done = false;
     }
-    // one step moves theta by at most max_speed*dt, so the new theta (observation) stays in range too
-    __device__ static bool fast_ok(const float* st, Action) { return (f2u(st[0]) & 0x7fffffffu) < 0x4d000000u; } // |theta| < 2^27
+    __device__ static bool fast_ok(const float* st, Action) { return in_short_range(st[0]); } // |theta| <= 200
     static constexpr int kVariants = 1;
     __device__ static int variant(const Consts&) { return 0; }
     template <int>
     __device__ static void advance_fast(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
-        reward = pendulum_advance<SinCosMedium>(c, st[0], st[1], a);
+        reward = pendulum_advance<SinCosShort>(c, st[0], st[1], a);
         done = false;
     }
     __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { pendulum_sample(r, b, st[0], st[1]); }
@@ -406,10 +405,10 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
         Vec<float, kVec> oc, os;
         bool med = true;
 #pragma unroll
-        for (int k = 0; k < kVec; ++k) med = med && in_medium_range(ls[0][k]);
+        for (int k = 0; k < kVec; ++k) med = med && in_short_range(ls[0][k]);
         if (__all(med)) {
 #pragma unroll
-            for (int k = 0; k < kVec; ++k) sincos_medium(ls[0][k], &os.v[k], &oc.v[k]);
+            for (int k = 0; k < kVec; ++k) sincos_short(ls[0][k], &os.v[k], &oc.v[k]);
         } else {
 #pragma unroll
             for (int k = 0; k < kVec; ++k) sincosf_(ls[0][k], &os.v[k], &oc.v[k]);

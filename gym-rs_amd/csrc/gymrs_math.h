@@ -10,8 +10,8 @@
 //   theta.cos()/theta.sin()   /root/reference/src/envs/classical_control/cartpole.rs:420-421
 //   (3*position).cos()        /root/reference/src/envs/classical_control/mountain_car.rs:412
 //
-// Accuracy (measured by tests/test_math_twin.py against f64 libm): <= 1.5 ulp over the whole f32
-// range, i.e. far inside the 1e-6 tolerance vs the f64 oracle.
+// Accuracy (tests/test_twin_vs_oracle.py against f64 libm): <= 1.6 ulp for |x| <= pi/4 and for |x| > 200,
+// <= 1.5e-7 absolute for pi/4 < |x| <= 200 (f32 reduction): far inside the 1e-6 tolerance vs the f64 oracle.
 #pragma once
 #include <stdint.h>
 
@@ -48,8 +48,25 @@ GYMRS_HD void sincos_poly(float r, float* s, float* c)
     *c = fmaf_(w, pc, fmaf_(z, -0.5f, 1.0f));
 }
 
+// f32 Cody-Waite reduction for |x| <= 200 (|k| <= 128): r = x - k*(P1 + P2), both steps one fma.  The first
+// fma forms x - k*P1 exactly and rounds once (|r| <= 0.8: error <= 3e-8 however large x is), the second adds
+// the k*P2 correction; the absolute error of r is <= 6e-8, so sin/cos come out within 1.5e-7 ABSOLUTE (not
+// within ulps near their zeros) - an order of magnitude inside the 1e-6 budget, at a third of the cost of
+// the f64 reduction below.  MountainCar's cos(3*position) and Pendulum's angles live here.
+GYMRS_HD int rem_pio2f_short(float x, float* r_out)
+{
+    const float two_over_pi = 0x1.45f306p-1f, P1 = 0x1.921fb6p+0f, P2 = -0x1.777a5cp-25f;
+    const float fn = __builtin_rintf(x * two_over_pi);
+    float r = fmaf_(-fn, P1, x);
+    r = fmaf_(-fn, P2, r);
+    *r_out = r;
+    return (int)fn;
+}
+GYMRS_HD bool in_short_range(float x) { return (__builtin_bit_cast(uint32_t, x) & 0x7fffffffu) <= 0x43480000u; } // |x| <= 200
+
 // Argument reduction x = k*(pi/2) + r, |r| <= pi/4.  Returns k (mod 4 is all that matters).
 //   |x| <= pi/4            : k = 0, r = x exactly (so callers may skip the reduction wave-wide)
+//   |x| <= 200             : f32 Cody-Waite (rem_pio2f_short)
 //   |x| <  2^28 * pi/2     : two-constant Cody-Waite in f64 with fma
 //   otherwise (finite)     : Payne-Hanek on a 224-bit table of 2/pi, integer arithmetic
 //   inf / NaN              : r = NaN
@@ -61,6 +78,7 @@ GYMRS_HD int rem_pio2f(float x, float* r_out)
         *r_out = x;
         return 0;
     }
+    if (ax <= 0x43480000u) return rem_pio2f_short(x, r_out); // |x| <= 200
     if (ax < 0x4dc90fdbu) { // |x| < 2^28 * pi/2
         const double invpio2 = 0x1.45f306dc9c883p-1;
         const double pio2_hi = 0x1.921fb54442d18p+0;
@@ -140,6 +158,15 @@ GYMRS_HD void sincos_medium(float x, float* s, float* c)
     sincos_poly((float)rd, &sr, &cr);
     sincos_quadrant((int)fn, sr, cr, s, c);
 }
+// Branch-free sin & cos for |x| <= 200; same bits as sincosf_ there (for |x| <= pi/4: fn = 0, r = x exactly).
+GYMRS_HD void sincos_short(float x, float* s, float* c)
+{
+    float r;
+    const int k = rem_pio2f_short(x, &r);
+    float sr, cr;
+    sincos_poly(r, &sr, &cr);
+    sincos_quadrant(k, sr, cr, s, c);
+}
 GYMRS_HD bool in_small_range(float x) { return (f2u(x) & 0x7fffffffu) <= 0x3f490fdbu; }  // |x| <= fl32(pi/4)
 GYMRS_HD bool in_medium_range(float x) { return (f2u(x) & 0x7fffffffu) < 0x4dc90fdbu; }  // |x| < 2^28*pi/2
 
@@ -147,6 +174,7 @@ GYMRS_HD bool in_medium_range(float x) { return (f2u(x) & 0x7fffffffu) < 0x4dc90
 struct SinCosGeneral { static GYMRS_HD void eval(float x, float* s, float* c); };
 struct SinCosSmall { static GYMRS_HD void eval(float x, float* s, float* c) { sincos_poly(x, s, c); } };
 struct SinCosMedium { static GYMRS_HD void eval(float x, float* s, float* c) { sincos_medium(x, s, c); } };
+struct SinCosShort { static GYMRS_HD void eval(float x, float* s, float* c) { sincos_short(x, s, c); } };
 
 // Full-range sin & cos.
 GYMRS_HD void sincosf_(float x, float* s, float* c)
