@@ -69,6 +69,7 @@ def main() -> int:
     ap.add_argument("--n-envs", type=int, default=0, help="lanes per GPU (default: the BASELINE config)")
     ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4, 8, 16); 0 = engine default")
     ap.add_argument("--nt", type=int, default=0, help="memory hint: 0 auto, 1 always non-temporal, 2 never")
+    ap.add_argument("--stats", action="store_true", help="pendulum: also track episode returns (dense accumulator)")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
@@ -100,7 +101,9 @@ def main() -> int:
     n = args.n_envs or n_default
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
     if args.env == "pendulum":
-        flags |= gymrs.TIME_LIMIT  # it never terminates; episodes end by the 200-step limit only
+        # It never terminates: episodes end by the 200-step time limit only.  Return tracking needs a dense
+        # per-lane accumulator for this env (+8 B per lane-step), so it is off unless --stats is given.
+        flags = gymrs.AUTO_RESET | gymrs.TIME_LIMIT | (gymrs.TRACK_STATS if args.stats else 0)
     eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags,
                               lanes_per_thread=args.vec or None)
     if args.nt:
@@ -193,7 +196,7 @@ def main() -> int:
                 "env": args.env,
                 "lanes_per_gpu": n,
                 "total_lanes": n * world,
-                "flags": "AUTO_RESET|TRACK_STATS" + ("|TIME_LIMIT" if args.env == "pendulum" else ""),
+                "flags": "|".join(nm for bit, nm in ((1, "AUTO_RESET"), (2, "TRACK_STATS"), (4, "TIME_LIMIT")) if flags & bit),
                 "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
                 "parallelism": f"lane-sharded x{world}, no data-path collective; 1 RCCL all-reduce of 4 f64 per run",
@@ -205,7 +208,7 @@ def main() -> int:
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
-                "kernel": "step_kernel<%s, AUTO|STATS%s>" % (args.env, "|TLIM" if args.env == "pendulum" else ""),
+                "kernel": "step_kernel<%s, 4, flags=%d>" % (args.env, flags),
                 "bytes_per_env_step": bytes_per_step,
                 "bytes_per_launch": n * bytes_per_step,
                 "launch_us": launch_us,

@@ -88,6 +88,8 @@ struct gymrs_engine {
     uint32_t epoch = 1;                       // ep_start value written by the last reset()
     void* action_staging = nullptr; // for gymrs_step_host
     uint64_t seed = 0, tick = 0;
+    uint64_t uniform_start = 0; // Pendulum: tick at which every lane's current episode started
+    uint32_t max_steps = 0;
     double n_steps_total = 0;
     void* comm = nullptr; // ncclComm_t
     int n_ranks = 1;
@@ -145,6 +147,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.seed = e->seed;
     a.tick = e->tick;
     a.box = make_sample_box(e->lo, e->hi, e->state_dim);
+    a.truncate_all = (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT) && e->tick + 1 - e->uniform_start >= e->max_steps) ? 1u : 0u;
     a.trace = e->trace;
     return a;
 }
@@ -370,6 +373,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
         gymrs_default_params(kind, &d);
         const auto& p = params ? *static_cast<const gymrs_pendulum_params*>(params) : d;
         e->consts.pd = make_consts(p);
+        e->max_steps = e->consts.pd.max_steps;
         e->max_torque = (float)p.max_torque;
         e->state_dim = 2;
         e->obs_dim = 3;
@@ -546,6 +550,7 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     a.box = make_sample_box(lo, hi, e->state_dim);
     HIP_TRY(launch_reset(e->kind, a, e->stream));
     e->tick += 1;
+    e->uniform_start = e->tick;
     e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
     // a reset discards the open episodes and starts the statistics afresh
     HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
@@ -561,6 +566,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     StepArgs a = step_args(e, actions_dev);
     HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
     e->tick += 1;
+    if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick; // all lanes were re-armed
     e->n_steps_total += (double)e->n;
     return GYMRS_OK;
 }
@@ -587,6 +593,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
         e->tick += 1;
+        if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
     }
     e->n_steps_total += (double)e->n * (double)n_steps;
     return GYMRS_OK;

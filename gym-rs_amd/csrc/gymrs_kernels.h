@@ -29,6 +29,7 @@ struct StepArgs {
     uint64_t seed;
     uint64_t tick;
     SampleBox box;      // reset sampling box, prepared on the host (gymrs_philox.h)
+    uint32_t truncate_all; // envs that never terminate (Pendulum): this step hits the time limit for every lane
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
 };
 

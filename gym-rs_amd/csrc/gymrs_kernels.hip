@@ -104,6 +104,7 @@ struct CartPoleT {
     static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
     static constexpr bool kHasBeyond = true;
     static constexpr bool kHasObsExtra = false;
+    static constexpr bool kNeverTerminates = false;
     __device__ static bool valid(Action a) { return a < 2; } // Discrete(2).contains, discrete.rs:14-19
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -130,6 +131,7 @@ struct MountainCarT {
     static constexpr bool kConstReward = true; // -1.0 on every step (mountain_car.rs:423)
     static constexpr bool kHasBeyond = false;
     static constexpr bool kHasObsExtra = false;
+    static constexpr bool kNeverTerminates = false;
     __device__ static bool valid(Action a) { return a < 3; } // Discrete(3)
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -155,6 +157,9 @@ struct PendulumT { // spec-derived, not in the reference
     static constexpr bool kConstReward = false;
     static constexpr bool kHasBeyond = false;
     static constexpr bool kHasObsExtra = true;
+    // No termination and no invalid actions: every lane's episode clock is the same, so the time limit is a
+    // kernel argument (StepArgs::truncate_all) instead of a per-lane compare against a dense ep_start read.
+    static constexpr bool kNeverTerminates = true;
     __device__ static bool valid(Action) { return true; } // a Box action is clipped, never rejected
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -198,7 +203,7 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
     for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, 0.0f);
     d.act = load_vec<Action, kVec, R::NT>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
     if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, uint8_t(0));
-    if (R::TLIM) d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
+    if (R::TLIM && !Env::kNeverTerminates) d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
     if (R::STATS && !Env::kConstReward) d.ep_ret = load_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, 0.0f);
 }
 
@@ -316,7 +321,10 @@ __device__ __forceinline__ void finish_tile(const StepArgs& a, const typename En
                 d.beyond.v[k] = b ? 1 : 0;
             }
         }
-        tr[k] = TLIM && stepped && (tick_next - d.ep_start.v[k]) >= c.max_steps;
+        if (Env::kNeverTerminates)
+            tr[k] = TLIM && stepped && a.truncate_all != 0;
+        else
+            tr[k] = TLIM && stepped && (tick_next - d.ep_start.v[k]) >= c.max_steps;
         if (STATS && !Env::kConstReward) d.ep_ret.v[k] += rw[k];
         done.v[k] = dn[k] ? 1 : 0;
         trunc.v[k] = tr[k] ? 1 : 0;
