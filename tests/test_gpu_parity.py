@@ -437,3 +437,58 @@ def test_custom_physics_params_and_semi_implicit_integrator(gymrs, oracle, twin,
     ref = st.astype(np.float64).copy()
     oracle.mountain_car_step_batch(ref, act, om)
     assert mixed_err(got, ref).max() <= TOL
+
+
+def test_external_stream_policy_to_step_without_host_sync(gymrs, twin):
+    """Drop-in use: the engine rides the host framework's HIP stream (gymrs_set_stream), so a policy that
+    produces actions on that stream feeds step() with no host synchronisation in between."""
+    n, steps = 65_536, 25
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    stream = torch.cuda.Stream()
+    eng = gymrs.BatchedEngine(gymrs.CARTPOLE, n, flags=flags)
+    eng.set_stream(stream.cuda_stream)
+    assert eng.stream == stream.cuda_stream
+    tw = TwinEngine(twin, 0, n, eng.params, flags=flags)
+    eng.reset(seed=3)
+    tw.reset(3)
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(1234)
+    history = []
+    with torch.cuda.stream(stream):
+        for t in range(steps):
+            # "policy": a torch op on the shared stream (here random, it could read eng.obs_ptrs())
+            a = torch.randint(0, 2, (n,), dtype=torch.uint8, device="cuda:0", generator=gen)
+            eng.step(a.data_ptr())
+            history.append(a)  # keep alive; copied back only after the loop
+    eng.sync()
+    for a in history:
+        tw.step(a.cpu().numpy())
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    assert np.array_equal(eng.stats(), tw.stats())
+    eng.close()
+
+
+def test_step_many_ring_pendulum_f32_actions(gymrs, twin):
+    n, steps, nbuf = 12_345, 45, 3
+    flags = gymrs.AUTO_RESET | gymrs.TIME_LIMIT | gymrs.TRACK_STATS
+    p = gymrs.engine.default_params(2)
+    p.max_episode_steps = 20
+    eng = gymrs.BatchedEngine(gymrs.PENDULUM, n, flags=flags, params=p)
+    tw = TwinEngine(twin, 2, n, p, flags=flags)
+    eng.reset(seed=9)
+    tw.reset(9)
+    bufs = torch.empty((nbuf, n), dtype=torch.float32, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(bufs[b].data_ptr(), seed=4, t=b)
+    eng.step_many(bufs.data_ptr(), n * 4, nbuf, steps)
+    eng.sync()
+    for t in range(steps):
+        tw.step(tw.fill_actions(4, t % nbuf))
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    assert np.array_equal(eng.get_obs().view(np.uint32), tw.get_obs().view(np.uint32))
+    gr, gd, gt = eng.get_step_result()
+    tr, td, tt = tw.get_result()
+    assert np.array_equal(gr.view(np.uint32), tr.view(np.uint32)) and np.array_equal(gt, tt) and not gd.any()
+    gs, ts = eng.stats(), tw.stats()
+    assert gs[1] == ts[1] == n * 40 and gs[2] == ts[2] == n * 2 and gs[0] == pytest.approx(ts[0], rel=1e-5)
+    eng.close()
