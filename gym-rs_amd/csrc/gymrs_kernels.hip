@@ -462,12 +462,23 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
 // (1 wave per SIMD).  More lanes per wave = fewer waves = fewer per-wave fixed costs (address set-up, the
 // auto-reset Philox pass, which costs the same whether 11 or 45 of its 64 lanes are active) at the price of
 // registers; waves_per_eu lets the allocator use them instead of spilling to chase occupancy.
+// The pointers and the lane count the first instructions of a wave need are separate scalar kernel parameters
+// placed first, so that kernel-argument preloading (-mllvm -amdgpu-kernarg-preload-count, see build.py) can
+// deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 template <class Env, int VEC, uint32_t FLAGS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
-    const StepArgs a, const typename Env::Consts c)
+    float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n, const StepArgs rest,
+    const typename Env::Consts c)
 {
     constexpr int LPB = kBlock * VEC;
     __shared__ ResetLds<Env, VEC> lds;
+    StepArgs a = rest;
+    a.s[0] = s0;
+    a.s[1] = s1;
+    a.s[2] = s2;
+    a.s[3] = s3;
+    a.action = action;
+    a.n = n;
     // workgroup-uniform: every workgroup but the last runs the unguarded body
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
         step_block<Env, VEC, FLAGS, true>(a, c, lds);
@@ -580,8 +591,8 @@ __global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned lo
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a,
-                       *static_cast<const typename Env::Consts*>(consts));
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
+                       a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }
 
