@@ -72,6 +72,7 @@ def main() -> int:
     ap.add_argument("--stats", action="store_true", help="pendulum: also track episode returns (dense accumulator)")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
+    ap.add_argument("--graph", action="store_true", help="replay captured HIP graphs (pays for small batches only)")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
     args = ap.parse_args()
 
@@ -119,7 +120,7 @@ def main() -> int:
         eng.fill_actions(actions[b].data_ptr(), seed=1, t=b)
     stride = actions.stride(0) * actions.element_size()
     eng.reset(seed=0)
-    eng.step_many(actions.data_ptr(), stride, nbuf, args.warmup)
+    eng.step_many(actions.data_ptr(), stride, nbuf, args.warmup, use_graph=args.graph)
     eng.sync()
     eng.stats_clear()
     if args.native_rccl and dist_on:
@@ -140,7 +141,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
-    eng.step_many(actions.data_ptr(), stride, nbuf, args.steps)
+    eng.step_many(actions.data_ptr(), stride, nbuf, args.steps, use_graph=args.graph)
     ev1.record(stream)
     if dist_on:
         if args.native_rccl:
@@ -199,6 +200,7 @@ def main() -> int:
                 "flags": "|".join(nm for bit, nm in ((1, "AUTO_RESET"), (2, "TRACK_STATS"), (4, "TIME_LIMIT")) if flags & bit),
                 "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
+                "hip_graph": bool(args.graph),
                 "parallelism": f"lane-sharded x{world}, no data-path collective; 1 RCCL all-reduce of 4 f64 per run",
             },
             "roofline": {

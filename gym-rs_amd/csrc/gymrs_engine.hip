@@ -91,6 +91,14 @@ struct gymrs_engine {
     uint64_t uniform_start = 0; // Pendulum: tick at which every lane's current episode started
     uint32_t max_steps = 0;
     double n_steps_total = 0;
+    // captured HIP graph of `graph_steps` consecutive steps (gymrs_step_many use_graph)
+    hipGraphExec_t graph_exec = nullptr;
+    const void* graph_actions = nullptr;
+    uint64_t graph_stride = 0;
+    uint32_t graph_nbuf = 0, graph_steps = 0, graph_flags = 0;
+    int graph_vec = 0;
+    uint64_t graph_seed = 0;
+    unsigned long long* tick_dev = nullptr;
     void* comm = nullptr; // ncclComm_t
     int n_ranks = 1;
 };
@@ -307,6 +315,8 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
     (void)hipFree(e->err);
+    if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+    (void)hipFree(e->tick_dev);
     (void)hipFree(e->stats_dev);
     (void)hipFree(e->stats_acc);
     (void)hipFree(e->stats_base);
@@ -445,6 +455,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->stats_dev, 4));
     chk(dev_alloc(&e->stats_acc, 3));
     chk(dev_alloc(&e->stats_base, 1));
+    chk(dev_alloc(&e->tick_dev, 1));
     if (st != GYMRS_OK) {
         std::string msg = g_last_error;
         gymrs_engine_destroy(e);
@@ -484,6 +495,10 @@ gymrs_status gymrs_set_stream(gymrs_engine* e, void* hip_stream)
     if (e->own_stream) HIP_TRY(hipStreamDestroy(e->stream));
     e->stream = static_cast<hipStream_t>(hip_stream);
     e->own_stream = false;
+    if (e->graph_exec) { // the cached graph was captured on the old stream's arguments only, but keep it simple
+        (void)hipGraphExecDestroy(e->graph_exec);
+        e->graph_exec = nullptr;
+    }
     return GYMRS_OK;
 }
 
@@ -530,6 +545,10 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     // seeding.rs:21-26: the generator is re-created on every reset
     e->seed = has_seed ? seed : os_entropy();
     e->tick = 0;
+    if (e->graph_exec) { // the reset box and the seed are baked into a captured graph
+        (void)hipGraphExecDestroy(e->graph_exec);
+        e->graph_exec = nullptr;
+    }
     if (seed_used) *seed_used = e->seed;
 
     ResetArgs a;
@@ -581,15 +600,76 @@ gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host)
     return gymrs_step(e, e->action_staging);
 }
 
+// Capture `steps` consecutive step launches into a HIP graph.  What changes from one replay to the next is
+// only the tick, so it is read from device memory (tick_dev) and bumped by a one-thread kernel at the end of
+// the graph; everything else (pointers, flags, reset box, seed) is baked in and part of the cache key.
+static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stride_bytes, uint32_t n_buffers, uint32_t steps)
+{
+    if (e->graph_exec) {
+        (void)hipGraphExecDestroy(e->graph_exec);
+        e->graph_exec = nullptr;
+    }
+    hipGraph_t graph = nullptr;
+    HIP_TRY(hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+    hipError_t err = hipSuccess;
+    for (uint32_t t = 0; t < steps && err == hipSuccess; ++t) {
+        StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
+        a.tick = t;
+        a.tick_base = e->tick_dev;
+        err = launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream);
+    }
+    if (err == hipSuccess) err = launch_tick_advance(e->tick_dev, steps, e->stream);
+    hipError_t end = hipStreamEndCapture(e->stream, &graph);
+    if (err != hipSuccess || end != hipSuccess) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return fail(GYMRS_EHIP, std::string("HIP graph capture: ") + hipGetErrorString(err != hipSuccess ? err : end));
+    }
+    err = hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess) return fail(GYMRS_EHIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(err));
+    e->graph_actions = base;
+    e->graph_stride = stride_bytes;
+    e->graph_nbuf = n_buffers;
+    e->graph_steps = steps;
+    e->graph_flags = launch_flags_of(e);
+    e->graph_vec = e->vec;
+    e->graph_seed = e->seed;
+    return GYMRS_OK;
+}
+
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes, uint32_t n_buffers,
                              uint32_t n_steps, int use_graph)
 {
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step_many: NULL argument");
     if (n_buffers == 0) return fail(GYMRS_EINVAL, "gymrs_step_many: n_buffers must be > 0");
-    if (use_graph) return fail(GYMRS_EINVAL, "gymrs_step_many: use_graph is reserved (must be 0)");
     HIP_TRY(hipSetDevice(e->device));
     const char* base = static_cast<const char*>(actions_dev);
-    for (uint32_t t = 0; t < n_steps; ++t) {
+    uint32_t done = 0;
+    // Graph replay pays when the step kernel is shorter than a host launch (~3 us: small batches).  The
+    // Pendulum time limit is a host-computed kernel argument, so that combination stays eager.
+    const bool graph_ok = use_graph && !(e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT));
+    if (use_graph && !graph_ok) return fail(GYMRS_EINVAL, "gymrs_step_many: use_graph is not available for Pendulum with GYMRS_TIME_LIMIT");
+    if (graph_ok) {
+        // a graph holds a whole number of passes over the action ring, at least 32 steps
+        const uint32_t per_graph = n_buffers * ((32 + n_buffers - 1) / n_buffers);
+        if (n_steps >= per_graph) {
+            const bool hit = e->graph_exec && e->graph_actions == base && e->graph_stride == stride_bytes &&
+                             e->graph_nbuf == n_buffers && e->graph_steps == per_graph && e->graph_flags == launch_flags_of(e) &&
+                             e->graph_vec == e->vec && e->graph_seed == e->seed;
+            if (!hit) {
+                if (gymrs_status st = build_graph(e, base, stride_bytes, n_buffers, per_graph)) return st;
+            }
+            const unsigned long long tick_now = e->tick;
+            HIP_TRY(hipMemcpyAsync(e->tick_dev, &tick_now, sizeof(tick_now), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream)); // tick_now is a stack variable; the copy must finish before return
+            while (n_steps - done >= per_graph) {
+                HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
+                done += per_graph;
+                e->tick += per_graph;
+            }
+        }
+    }
+    for (uint32_t t = done; t < n_steps; ++t) { // eager launches (and the remainder after graph replays)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
         e->tick += 1;

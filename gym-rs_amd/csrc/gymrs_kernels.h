@@ -27,7 +27,8 @@ struct StepArgs {
     uint64_t n;         // lanes in this engine
     uint64_t gid0;      // global id of lane 0
     uint64_t seed;
-    uint64_t tick;
+    uint64_t tick;      // engine tick of this launch; when tick_base != NULL it is an OFFSET added to *tick_base
+    const unsigned long long* tick_base; // device-resident tick for captured HIP graphs (NULL in eager launches)
     SampleBox box;      // reset sampling box, prepared on the host (gymrs_philox.h)
     uint32_t truncate_all; // envs that never terminate (Pendulum): this step hits the time limit for every lane
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
@@ -57,6 +58,7 @@ inline uint32_t step_grid(uint64_t n, int vec)
 hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
                        hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
+hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);
 struct StatsArgs {

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 16 / 
     a.s[3] = s3;
     a.action = action;
     a.n = n;
+    if (rest.tick_base) a.tick = rest.tick + *rest.tick_base; // replayed HIP graph: the tick lives on the device
     // workgroup-uniform: every workgroup but the last runs the unguarded body
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
         step_block<Env, VEC, FLAGS, true>(a, c, lds);
@@ -640,6 +641,14 @@ hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepA
     case GYMRS_PENDULUM: return launch_vec<PendulumT>(vec, flags, a, consts, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+__global__ void tick_advance_kernel(unsigned long long* tick_dev, unsigned long long by) { *tick_dev += by; }
+
+hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, stream, tick_dev, by);
+    return hipGetLastError();
 }
 
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream)

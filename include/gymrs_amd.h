@@ -141,7 +141,10 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev);
 /* Same with a host action buffer (copied first); for the single-env compatibility layer. */
 gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host);
 /* n_steps consecutive step() calls; step t reads its actions at
- * actions_dev + (t % n_buffers) * stride_bytes.  use_graph != 0 replays a captured HIP graph. */
+ * actions_dev + (t % n_buffers) * stride_bytes.  use_graph != 0 replays a captured HIP graph of >= 32 steps
+ * (a whole number of passes over the action ring; the remainder is launched eagerly): worth it when the step
+ * kernel is shorter than a host launch (~3 us, i.e. small batches); results are identical.  Not available
+ * for Pendulum with GYMRS_TIME_LIMIT (GYMRS_EINVAL). */
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes,
                              uint32_t n_buffers, uint32_t n_steps, int use_graph);
 /* Wait for the stream; returns GYMRS_EACTION if any step since the last sync saw an invalid action. */

@@ -144,6 +144,52 @@ def test_step_many_equals_repeated_step(gymrs, twin):
     assert eng.tick()[0] == steps + 1
     eng.close()
 
+@pytest.mark.parametrize("kind,nbuf,steps", [(0, 4, 75), (1, 5, 83), (0, 48, 100)])
+def test_step_many_graph_replay_is_bit_identical(gymrs, twin, kind, nbuf, steps):
+    """use_graph=1 replays captured graphs of >=32 steps with a device-resident tick; the result (state,
+    per-step outputs of the last step, statistics, tick) must equal eager stepping bit for bit, across two
+    calls (second call reuses the cached graph) and a remainder."""
+    n = 3000
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | gymrs.TIME_LIMIT
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 40
+    eng = gymrs.BatchedEngine(kind, n, flags=flags, params=p)
+    tw = TwinEngine(twin, kind, n, p, flags=flags)
+    eng.reset(seed=21)
+    tw.reset(21)
+    bufs = torch.empty((nbuf, n), dtype=torch.uint8, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(bufs[b].data_ptr(), seed=8, t=b)
+    for call in range(2):
+        eng.step_many(bufs.data_ptr(), n, nbuf, steps, use_graph=True)
+        eng.sync()
+        for t in range(steps):
+            tw.step(tw.fill_actions(8, t % nbuf))
+        assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32)), call
+        gr, gd, gt = eng.get_step_result()
+        tr, td, tt = tw.get_result()
+        assert np.array_equal(gr.view(np.uint32), tr.view(np.uint32)) and np.array_equal(gd, td) and np.array_equal(gt, tt)
+        assert np.array_equal(eng.stats(), tw.stats())
+        assert eng.tick()[0] == (call + 1) * steps + 1
+    # a reset invalidates the cached graph (seed and reset box are baked into it)
+    eng.reset(seed=22)
+    tw.reset(22)
+    eng.step_many(bufs.data_ptr(), n, nbuf, steps, use_graph=True)
+    for t in range(steps):
+        tw.step(tw.fill_actions(8, t % nbuf))
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    assert np.array_equal(eng.stats(), tw.stats())
+    eng.close()
+
+
+def test_step_many_graph_refused_for_pendulum_time_limit(gymrs):
+    eng = gymrs.BatchedEngine(gymrs.PENDULUM, 256, flags=gymrs.AUTO_RESET | gymrs.TIME_LIMIT)
+    eng.reset(seed=1)
+    bufs = torch.zeros((1, 256), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(gymrs.GymrsError):
+        eng.step_many(bufs.data_ptr(), 1024, 1, 64, use_graph=True)
+    eng.close()
+
 
 def test_golden_vectors_on_gpu(gymrs, golden):
     cp = golden("cartpole")
