@@ -72,6 +72,9 @@ def main() -> int:
     ap.add_argument("--stats", action="store_true", help="pendulum: also track episode returns (dense accumulator)")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
+    ap.add_argument("--rollout", type=int, default=0, metavar="R",
+                    help="NOT the headline: fused gymrs_rollout launches of R steps each (state stays in registers, "
+                         "observations of intermediate steps are not materialised); reported with mode=fused_rollout")
     ap.add_argument("--graph", action="store_true", help="replay captured HIP graphs (pays for small batches only)")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
     args = ap.parse_args()
@@ -120,7 +123,18 @@ def main() -> int:
         eng.fill_actions(actions[b].data_ptr(), seed=1, t=b)
     stride = actions.stride(0) * actions.element_size()
     eng.reset(seed=0)
-    eng.step_many(actions.data_ptr(), stride, nbuf, args.warmup, use_graph=args.graph)
+
+    def run(k):
+        if args.rollout:
+            done = 0
+            while done < k:
+                r = min(args.rollout, k - done)
+                eng.rollout(r, action_seed=1, action_t0=done)
+                done += r
+        else:
+            eng.step_many(actions.data_ptr(), stride, nbuf, k, use_graph=args.graph)
+
+    run(args.warmup)
     eng.sync()
     eng.stats_clear()
     if args.native_rccl and dist_on:
@@ -141,7 +155,7 @@ def main() -> int:
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev0.record(stream)
-    eng.step_many(actions.data_ptr(), stride, nbuf, args.steps, use_graph=args.graph)
+    run(args.steps)
     ev1.record(stream)
     if dist_on:
         if args.native_rccl:
@@ -218,6 +232,16 @@ def main() -> int:
             },
             "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},
         }
+        if args.rollout:
+            # the fused kernel touches HBM once per launch of R steps: it is VALU-bound, the HBM roofline of the
+            # per-step kernel does not apply and is not claimed
+            out["mode"] = "fused_rollout"
+            out["config"]["steps_per_launch"] = args.rollout
+            out["config"]["workload"] = workload + f" -- fused rollout, {args.rollout} steps per launch (NOT the per-step headline)"
+            out["roofline"] = {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                               "kernel": "rollout_kernel<%s, 4, flags=%d>" % (args.env, flags),
+                               "launch_us": kernel_ms * 1e3 / max(1, -(-args.steps // args.rollout)),
+                               "ns_per_lane_step": kernel_ms * 1e6 / args.steps / n}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gymrs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gymrs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gymrs_allreduce_stats": (C.c_int, [C.c_void_p, f64p]),
+    "gymrs_rollout": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "gymrs_fill_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gymrs_get_tick": (C.c_int, [C.c_void_p, u64p, u64p]),
     "gymrs_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

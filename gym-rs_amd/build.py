@@ -21,9 +21,10 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 ORACLE = ROOT / "oracle"
 
-HIP_SOURCES = [CSRC / "gymrs_kernels.hip", CSRC / "gymrs_engine.hip"]
+HIP_SOURCES = [CSRC / "gymrs_kernels.hip", CSRC / "gymrs_rollout.hip", CSRC / "gymrs_engine.hip"]
 HIP_HEADERS = [
     CSRC / "gymrs_kernels.h",
+    CSRC / "gymrs_tile.h",
     CSRC / "gymrs_physics.h",
     CSRC / "gymrs_philox.h",
     CSRC / "gymrs_math.h",
@@ -39,7 +40,6 @@ HIPCC_FLAGS = [
     "-std=c++17",
     "-ffp-contract=off",
     "-fPIC",
-    "-shared",
     "-Wall",
     "-Wno-unused-function",
     # Deliver the first 12 dwords of kernel arguments (step_kernel: 4 state pointers, the action pointer, n)
@@ -69,13 +69,26 @@ def _run(cmd, cwd=None):
     subprocess.run([str(c) for c in cmd], cwd=cwd, check=True)
 
 
-def build_hip(force: bool = False) -> Path:
-    deps = HIP_SOURCES + HIP_HEADERS + [Path(__file__)]
-    if not force and _newer(LIB, deps):
-        return LIB
-    cmd = [_hipcc(), *HIPCC_FLAGS, f"-I{ROOT / 'include'}", f"-I{CSRC}", *HIP_SOURCES, "-o", LIB, "-ldl"]
-    _run(cmd)
-    return LIB
+def build_hip(force: bool = False, extra_flags=(), out: Path | None = None) -> Path:
+    """One object per translation unit (compiled concurrently: the kernel tables take minutes), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    lib = Path(out) if out else LIB
+    objdir = lib.parent / "_obj" / lib.stem
+    hdr_deps = HIP_HEADERS + [Path(__file__)]
+    if not force and not extra_flags and _newer(lib, HIP_SOURCES + hdr_deps):
+        return lib
+    objdir.mkdir(parents=True, exist_ok=True)
+    hipcc = _hipcc()
+    jobs = []
+    for src in HIP_SOURCES:
+        obj = objdir / (src.stem + ".o")
+        if force or extra_flags or not _newer(obj, [src] + hdr_deps):
+            jobs.append([hipcc, *HIPCC_FLAGS, *extra_flags, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-c", src, "-o", obj])
+    with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
+        list(pool.map(_run, jobs))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(objdir / (s.stem + ".o") for s in HIP_SOURCES), "-o", lib, "-ldl"])
+    return lib
 
 
 def build_oracle(force: bool = False) -> Path:

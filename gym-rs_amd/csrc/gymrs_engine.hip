@@ -590,6 +590,33 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     return GYMRS_OK;
 }
 
+// The caller loop of the reference's examples (examples/cartpole.rs:15-30: random action, step, reset on
+// done, accumulate the return) fused into one launch; see rollout_kernel.
+gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_rollout: NULL engine");
+    if (n_steps == 0) return GYMRS_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    StepArgs a = step_args(e, nullptr);
+    RolloutArgs r;
+    r.action_seed = action_seed;
+    r.action_t0 = action_t0;
+    r.uniform_start = e->uniform_start;
+    r.n_steps = n_steps;
+    r.n_actions = e->kind == GYMRS_CARTPOLE ? 2u : 3u;
+    r.max_torque = e->max_torque;
+    const int vec = e->vec == 8 ? 8 : 4;
+    HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
+    for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
+        e->tick += 1;
+        if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT) && (e->flags & GYMRS_AUTO_RESET) &&
+            e->tick - e->uniform_start >= e->max_steps)
+            e->uniform_start = e->tick;
+    }
+    e->n_steps_total += (double)e->n * (double)n_steps;
+    return GYMRS_OK;
+}
+
 gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host)
 {
     if (!e || !actions_host) return fail(GYMRS_EINVAL, "gymrs_step_host: NULL argument");

@@ -34,6 +34,16 @@ struct StepArgs {
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
 };
 
+// The fused multi-step kernel (gymrs_rollout): n_steps consecutive steps of every lane in ONE launch, with
+// the random-policy actions of gymrs_fill_actions(action_seed, action_t0 + k) generated in registers.
+struct RolloutArgs {
+    uint64_t action_seed, action_t0;
+    uint64_t uniform_start; // Pendulum time limit: the tick at which every lane's current episode started
+    uint32_t n_steps;
+    uint32_t n_actions;     // Discrete(n) envs
+    float max_torque;       // Pendulum
+};
+
 struct ResetArgs {
     float* s[4];
     float* obs_cos;
@@ -57,6 +67,8 @@ inline uint32_t step_grid(uint64_t n, int vec)
 
 hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
                        hipStream_t stream);
+hipError_t launch_rollout(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const RolloutArgs& r,
+                          const void* consts, hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,

@@ -30,405 +30,9 @@
 //     tick its next episode starts at (episodes tile a lane's time axis, so the sum of finished lengths
 //     is sum(ep_start) - n*epoch, evaluated when statistics are read) and every wave keeps a private
 //     episode counter slot (plain load at start, plain store at end; no atomics).
-#include <type_traits>
-
-#include "gymrs_kernels.h"
+#include "gymrs_tile.h"
 
 namespace gymrs {
-
-
-// Developer instrumentation (tools/probe --trace): per-wave s_memtime stamps at the phase boundaries.
-#ifdef GYMRS_TRACE_TIMES
-#define GYMRS_STAMP(slot_)                                                                                   \
-    do {                                                                                                     \
-        if (a.trace && (threadIdx.x & 63u) == 0)                                                             \
-            a.trace[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
-    } while (0)
-#else
-#define GYMRS_STAMP(slot_) do { } while (0)
-#endif
-
-// ---------------------------------------------------------------------------------------------
-// vector access helpers
-template <class T, int V>
-struct alignas(sizeof(T) * V) Vec {
-    T v[V];
-};
-
-// NT = the accesses carry the non-temporal hint.  Every array is read once and written once per step and
-// the next reader is the NEXT kernel (a kernel boundary flushes/invalidates the per-XCD L2s anyway), so
-// nothing is gained by keeping the lines in L2: measured -0.4 us per 2^20-lane launch.  The hint also keeps
-// the lines out of the 256 MB Infinity Cache, which is what serves the next step's reads while the working
-// set fits there, so above ~2^20 CartPole lanes plain accesses win again; the engine picks per launch.
-template <class T, int V, bool NT>
-__device__ __forceinline__ Vec<T, V> load_vec(const T* __restrict__ p, uint64_t base, uint64_t n, bool full, T fill)
-{
-    typedef T vt __attribute__((ext_vector_type(V)));
-    Vec<T, V> r;
-    if (full) {
-        const vt x = NT ? __builtin_nontemporal_load(reinterpret_cast<const vt*>(p + base)) : *reinterpret_cast<const vt*>(p + base);
-#pragma unroll
-        for (int k = 0; k < V; ++k) r.v[k] = x[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < V; ++k) r.v[k] = (base + k < n) ? p[base + k] : fill;
-    }
-    return r;
-}
-
-template <class T, int V, bool NT>
-__device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint64_t n, bool full, const Vec<T, V>& r)
-{
-    typedef T vt __attribute__((ext_vector_type(V)));
-    if (full) {
-        vt x;
-#pragma unroll
-        for (int k = 0; k < V; ++k) x[k] = r.v[k];
-        if (NT)
-            __builtin_nontemporal_store(x, reinterpret_cast<vt*>(p + base));
-        else
-            *reinterpret_cast<vt*>(p + base) = x;
-    } else {
-#pragma unroll
-        for (int k = 0; k < V; ++k)
-            if (base + k < n) p[base + k] = r.v[k];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Env policies: what differs between the three env types.
-struct CartPoleT {
-    using Consts = CartPoleConsts;
-    using Action = uint8_t;
-    static constexpr int kState = 4;
-    static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
-    static constexpr bool kHasBeyond = true;
-    static constexpr bool kHasObsExtra = false;
-    static constexpr bool kNeverTerminates = false;
-    __device__ static bool valid(Action a) { return a < 2; } // Discrete(2).contains, discrete.rs:14-19
-    __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        done = cartpole_advance(c, st[0], st[1], st[2], st[3], a);
-        reward = 1.0f; // the beyond-terminated case is applied by the caller when auto-reset is off
-    }
-    // branch-free variant, legal when fast_ok holds (|theta| <= pi/4: the polynomial needs no reduction)
-    __device__ static bool fast_ok(const float* st, Action a) { return a < 2 && in_small_range(st[2]); }
-    static constexpr int kVariants = 2; // the integrator choice is hoisted out of the per-lane code
-    __device__ static int variant(const Consts& c) { return c.integrator == 0 ? 0 : 1; }
-    template <int INTEG>
-    __device__ static void advance_fast(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        done = cartpole_advance<SinCosSmall, INTEG>(c, st[0], st[1], st[2], st[3], a);
-        reward = 1.0f;
-    }
-    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { cartpole_sample(r, b, st[0], st[1], st[2], st[3]); }
-};
-
-struct MountainCarT {
-    using Consts = MountainCarConsts;
-    using Action = uint8_t;
-    static constexpr int kState = 2;
-    static constexpr bool kConstReward = true; // -1.0 on every step (mountain_car.rs:423)
-    static constexpr bool kHasBeyond = false;
-    static constexpr bool kHasObsExtra = false;
-    static constexpr bool kNeverTerminates = false;
-    __device__ static bool valid(Action a) { return a < 3; } // Discrete(3)
-    __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        done = mountain_car_advance(c, st[0], st[1], a);
-        reward = -1.0f;
-    }
-    __device__ static bool fast_ok(const float* st, Action a) { return a < 3 && in_short_range(3.0f * st[0]); }
-    static constexpr int kVariants = 1;
-    __device__ static int variant(const Consts&) { return 0; }
-    template <int>
-    __device__ static void advance_fast(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        done = mountain_car_advance<SinCosShort>(c, st[0], st[1], a);
-        reward = -1.0f;
-    }
-    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { mountain_car_sample(r, b, st[0], st[1]); }
-};
-
-struct PendulumT { // spec-derived, not in the reference
-    using Consts = PendulumConsts;
-    using Action = float;
-    static constexpr int kState = 2;
-    static constexpr bool kConstReward = false;
-    static constexpr bool kHasBeyond = false;
-    static constexpr bool kHasObsExtra = true;
-    // No termination and no invalid actions: every lane's episode clock is the same, so the time limit is a
-    // kernel argument (StepArgs::truncate_all) instead of a per-lane compare against a dense ep_start read.
-    static constexpr bool kNeverTerminates = true;
-    __device__ static bool valid(Action) { return true; } // a Box action is clipped, never rejected
-    __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        reward = pendulum_advance(c, st[0], st[1], a);
-        done = false;
-    }
-    __device__ static bool fast_ok(const float* st, Action) { return in_short_range(st[0]); } // |theta| <= 200
-    static constexpr int kVariants = 1;
-    __device__ static int variant(const Consts&) { return 0; }
-    template <int>
-    __device__ static void advance_fast(const Consts& c, float* st, Action a, float& reward, bool& done)
-    {
-        reward = pendulum_advance<SinCosShort>(c, st[0], st[1], a);
-        done = false;
-    }
-    __device__ static void sample(const u32x4& r, const SampleBox& b, float* st) { pendulum_sample(r, b, st[0], st[1]); }
-};
-
-// ---------------------------------------------------------------------------------------------
-// THE hot kernel: one Env::step() per lane; a work-item owns VEC lanes, a wavefront 64*VEC, a workgroup 256*VEC.
-template <class Env, int VEC, uint32_t FLAGS>
-struct TileRegs {
-    static constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
-    static constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
-    static constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
-    static constexpr bool NT = (FLAGS & kFlagNonTemporal) != 0;
-    Vec<float, VEC> st[Env::kState];
-    Vec<typename Env::Action, VEC> act;
-    Vec<uint8_t, VEC> beyond;
-    Vec<uint32_t, VEC> ep_start;
-    Vec<float, VEC> ep_ret;
-};
-
-template <class Env, int VEC, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, TileRegs<Env, VEC, FLAGS>& d)
-{
-    constexpr int kVec = VEC;
-    using R = TileRegs<Env, VEC, FLAGS>;
-    using Action = typename Env::Action;
-#pragma unroll
-    for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, 0.0f);
-    d.act = load_vec<Action, kVec, R::NT>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
-    if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, uint8_t(0));
-    if (R::TLIM && !Env::kNeverTerminates) d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
-    if (R::STATS && !Env::kConstReward) d.ep_ret = load_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, 0.0f);
-}
-
-// LDS of one workgroup for the auto-reset hand-off: every wavefront uses its own 256-entry segment
-// (list of finished lanes, their fresh states, their finished returns); waves never touch each other's.
-template <class Env, int VEC>
-struct ResetLds {
-    static constexpr int kLanes = kBlock * VEC;
-    uint16_t list[kLanes];
-    struct alignas(Env::kState * 4) State {
-        float v[Env::kState];
-    };
-    State fresh[kLanes]; // one ds_write/ds_read of 8 or 16 bytes per finished lane
-    float ret[Env::kConstReward ? 1 : kLanes];
-};
-
-// The branch-free physics of the 4 lanes of a work-item in one basic block (V = Env variant).
-template <class Env, int VEC, int V>
-__device__ __forceinline__ void advance_fast_all(const typename Env::Consts& c, float (&ls)[Env::kState][VEC],
-                                                 const typename Env::Action (&la)[VEC], float (&rw)[VEC], bool (&dn)[VEC])
-{
-    constexpr int kVec = VEC;
-    constexpr int NS = Env::kState;
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) {
-        float lane_st[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) lane_st[j] = ls[j][k];
-        Env::template advance_fast<V>(c, lane_st, la[k], rw[k], dn[k]);
-#pragma unroll
-        for (int j = 0; j < NS; ++j) ls[j][k] = lane_st[j];
-    }
-}
-
-// physics + auto-reset selection + stores of one tile whose loads were issued by load_tile
-template <class Env, int VEC, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void finish_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
-                                            TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC>& lds, unsigned long long old_resets,
-                                            double old_ret)
-{
-    constexpr int kVec = VEC;
-    using R = TileRegs<Env, VEC, FLAGS>;
-    constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
-    constexpr int NS = Env::kState;
-    using Action = typename Env::Action;
-    const uint32_t tick_next = (uint32_t)(a.tick + 1);
-
-    // ---- physics ----
-    // State is unpacked into plain per-lane scalars (registers) for the arithmetic and re-packed
-    // into vectors only for the stores.
-    float ls[NS][kVec];
-    Action la[kVec];
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) {
-        la[k] = d.act.v[k];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) ls[j][k] = d.st[j].v[k];
-    }
-    float rw[kVec];
-    bool dn[kVec], tr[kVec], need_reset[kVec];
-#ifdef GYMRS_TRACE_TIMES
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    GYMRS_STAMP(2); // all loads have landed
-#endif
-    bool fast = FULL;
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) {
-        float lane_st[NS];
-#pragma unroll
-        for (int j = 0; j < NS; ++j) lane_st[j] = ls[j][k];
-        fast = fast && Env::fast_ok(lane_st, la[k]);
-    }
-    if (__all(fast)) { // wave-uniform: the common path
-        if (Env::kVariants == 1 || Env::variant(c) == 0)
-            advance_fast_all<Env, VEC, 0>(c, ls, la, rw, dn);
-        else
-            advance_fast_all<Env, VEC, 1>(c, ls, la, rw, dn);
-    } else { // general per-lane code: ragged tail, invalid actions, angles outside the fast range
-        uint32_t n_bad = 0, first_bad = 0xffffffffu;
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) {
-            const bool live = FULL || (base + k < a.n);
-            const bool ok = Env::valid(la[k]);
-            float lane_st[NS];
-#pragma unroll
-            for (int j = 0; j < NS; ++j) lane_st[j] = ls[j][k];
-            float r = 0.0f;
-            bool dk = false;
-            if (live && ok) {
-                Env::advance(c, lane_st, la[k], r, dk);
-            } else if (live) { // invalid action: the reference panics before touching the env
-                n_bad += 1;
-                first_bad = min(first_bad, (uint32_t)(base + k));
-            }
-#pragma unroll
-            for (int j = 0; j < NS; ++j) ls[j][k] = lane_st[j];
-            rw[k] = r;
-            dn[k] = dk;
-        }
-        if (n_bad) {
-            atomicAdd(&a.err[0], n_bad);
-            atomicMin(&a.err[1], first_bad);
-        }
-    }
-    GYMRS_STAMP(3); // physics done
-    Vec<uint8_t, kVec> done, trunc;
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) {
-        const bool stepped = (FULL || (base + k < a.n)) && Env::valid(la[k]);
-        if (Env::kHasBeyond && !AUTO) { // cartpole.rs:455-464
-            bool b = d.beyond.v[k] != 0;
-            const float r = cartpole_reward(dn[k], b);
-            if (stepped) {
-                rw[k] = r;
-                d.beyond.v[k] = b ? 1 : 0;
-            }
-        }
-        if (Env::kNeverTerminates)
-            tr[k] = TLIM && stepped && a.truncate_all != 0;
-        else
-            tr[k] = TLIM && stepped && (tick_next - d.ep_start.v[k]) >= c.max_steps;
-        if (STATS && !Env::kConstReward) d.ep_ret.v[k] += rw[k];
-        done.v[k] = dn[k] ? 1 : 0;
-        trunc.v[k] = tr[k] ? 1 : 0;
-        need_reset[k] = AUTO && (dn[k] || tr[k]);
-    }
-
-    // ---- auto-reset: wave __ballot done-mask -> LDS-staged Philox, all inside one wavefront ----
-    if (AUTO) {
-        constexpr int LPW = 64 * kVec; // lanes per wavefront = capacity of a wave's LDS segment
-        const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-        uint16_t* list = lds.list + wave * LPW; // this wave's compacted list of finished lanes
-        uint32_t slot[kVec];
-        uint32_t total = 0; // finished lanes of this wave (wave-uniform)
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) {
-            const unsigned long long m = __ballot(need_reset[k]);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            slot[k] = total + rank;
-            if (need_reset[k]) {
-                list[slot[k]] = (uint16_t)(lane * kVec + k); // wave-local lane
-                if (STATS && !Env::kConstReward) lds.ret[wave * LPW + slot[k]] = d.ep_ret.v[k];
-            }
-            total += (uint32_t)__popcll(m);
-        }
-        if (total != 0) { // quiet waves (MountainCar / Pendulum: nearly all) skip everything below
-            // DS operations of one wavefront execute in order: no barrier is needed, only the compiler
-            // must not move LDS accesses across the hand-over points.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const uint64_t wave_base = (uint64_t)blockIdx.x * (kBlock * kVec) + (uint64_t)wave * LPW;
-            float ret_sum = 0.0f;
-            for (uint32_t i = lane; i < total; i += 64u) { // one Philox4x32-10 block per finished lane
-                const uint64_t gl = wave_base + list[i];
-                const u32x4 r = draw4(a.seed, a.gid0 + gl, a.tick, kStreamReset);
-                float ns[NS];
-                Env::sample(r, a.box, ns);
-                typename ResetLds<Env, VEC>::State fs;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
-                lds.fresh[wave * LPW + i] = fs;
-                if (STATS || TLIM) a.ep_start[gl] = tick_next; // the new episode starts at the next tick (plain store:
-                                                               // a non-temporal scattered dword store measured slower)
-                if (STATS && !Env::kConstReward) ret_sum += lds.ret[wave * LPW + i]; // return of the finished episode
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int k = 0; k < kVec; ++k) {
-                if (need_reset[k]) {
-                    const typename ResetLds<Env, VEC>::State fs = lds.fresh[wave * LPW + slot[k]];
-#pragma unroll
-                    for (int j = 0; j < NS; ++j) ls[j][k] = fs.v[j];
-                    if (STATS && !Env::kConstReward) d.ep_ret.v[k] = 0.0f;
-                }
-            }
-            if (STATS) { // the wave's private statistics slot: plain read-modify-write, no atomics
-                unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (kBlock / 64) + wave) * 2;
-                if (!Env::kConstReward) {
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) ret_sum += __shfl_xor(ret_sum, off);
-                    if (lane == 0) reinterpret_cast<double*>(bs)[1] = old_ret + (double)ret_sum;
-                }
-                if (lane == 0) bs[0] = old_resets + total;
-            }
-        }
-    }
-
-    GYMRS_STAMP(4); // auto-reset done
-    // ---- stores ----
-    Vec<float, kVec> reward;
-#pragma unroll
-    for (int k = 0; k < kVec; ++k) reward.v[k] = rw[k];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        Vec<float, kVec> out;
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) out.v[k] = ls[j][k];
-        store_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, out);
-    }
-    store_vec<float, kVec, R::NT>(a.reward, base, a.n, FULL, reward);
-    store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, done);
-    if (TLIM) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, trunc);
-    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, d.beyond);
-    if (STATS && !Env::kConstReward) store_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, d.ep_ret);
-    if (Env::kHasObsExtra) {
-        Vec<float, kVec> oc, os;
-        bool med = true;
-#pragma unroll
-        for (int k = 0; k < kVec; ++k) med = med && in_short_range(ls[0][k]);
-        if (__all(med)) {
-#pragma unroll
-            for (int k = 0; k < kVec; ++k) sincos_short(ls[0][k], &os.v[k], &oc.v[k]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < kVec; ++k) sincosf_(ls[0][k], &os.v[k], &oc.v[k]);
-        }
-        store_vec<float, kVec, R::NT>(a.obs_cos, base, a.n, FULL, oc);
-        store_vec<float, kVec, R::NT>(a.obs_sin, base, a.n, FULL, os);
-    }
-    GYMRS_STAMP(5); // stores issued
-#ifdef GYMRS_TRACE_TIMES
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-}
 
 template <class Env, int VEC, uint32_t FLAGS, bool FULL>
 __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
@@ -454,7 +58,9 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
         if (!Env::kConstReward) old_ret = reinterpret_cast<const double*>(bs)[1];
     }
     GYMRS_STAMP(1);
-    finish_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret);
+    StepOut<VEC> out;
+    advance_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret, out);
+    store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out);
     GYMRS_STAMP(6);
 }
 
@@ -521,11 +127,10 @@ __global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Acti
 {
     const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (lane >= n) return;
-    const u32x4 r = draw4(seed, gid0 + lane, t, kStreamAction);
     if constexpr (sizeof(typename Env::Action) == 1) {
-        out[lane] = (uint8_t)(((uint64_t)r.v[0] * n_actions) >> 32);
+        out[lane] = action_discrete(seed, gid0 + lane, t, n_actions);
     } else {
-        out[lane] = uniform_between(r.v[0], -max_torque, max_torque);
+        out[lane] = uniform_between(action_word(seed, gid0 + lane, t), -max_torque, max_torque);
     }
 }
 

@@ -53,6 +53,25 @@ GYMRS_HD u32x4 draw4(uint64_t seed, uint64_t gid, uint64_t tick, uint32_t stream
                          (uint32_t)(seed >> 32));
 }
 
+// Random-policy action stream (stream 1; examples/cartpole.rs:19 `rng.gen_range(0..=1)`).  Four neighbouring
+// lanes share one Philox block per time slot -- lane gid takes word (gid & 3) of block (gid >> 2, slot) -- so
+// a work-item that owns 4 aligned lanes evaluates ONE block for all of them:
+//   Box actions (Pendulum):   slot = t,       action = uniform_between(word, low, high)   (24 random bits)
+//   Discrete(n) actions:      slot = t >> 1,  the 16-bit half (t & 1) of the word,  action = (half * n) >> 16
+// (16 bits: exact for n = 2; for n = 3 the three actions have probabilities 21846, 21845, 21845 / 65536).
+GYMRS_HD u32x4 action_block(uint64_t seed, uint64_t gid, uint64_t slot) { return draw4(seed, gid >> 2, slot, kStreamAction); }
+GYMRS_HD uint32_t pick_word(const u32x4& b, uint32_t j) { return j == 0 ? b.v[0] : (j == 1 ? b.v[1] : (j == 2 ? b.v[2] : b.v[3])); }
+GYMRS_HD uint32_t action_word(uint64_t seed, uint64_t gid, uint64_t t) { return pick_word(action_block(seed, gid, t), (uint32_t)gid & 3u); }
+GYMRS_HD uint8_t discrete_from_word(uint32_t word, uint64_t t, uint32_t n_actions)
+{
+    const uint32_t half = (word >> (((uint32_t)t & 1u) * 16u)) & 0xffffu;
+    return (uint8_t)((half * n_actions) >> 16);
+}
+GYMRS_HD uint8_t action_discrete(uint64_t seed, uint64_t gid, uint64_t t, uint32_t n_actions)
+{
+    return discrete_from_word(action_word(seed, gid, t >> 1), t, n_actions);
+}
+
 // u32 -> uniform f32 on [low, high): 24 random bits, u * scale + low, kept below `high` (half-open like
 // rand's Uniform::new, cartpole.rs:363).  Everything that does not depend on the random word is prepared
 // once on the host: v = min(fma(float(r >> 8), scale24, low), high_prev), scale24 = (high - low) * 2^-24,

@@ -269,6 +269,12 @@ class BatchedEngine:
         return np.array(out[:], dtype=np.float64)
 
     # -- utilities -----------------------------------------------------------------------------------
+    def rollout(self, n_steps: int, action_seed: int, action_t0: int = 0) -> None:
+        """``n_steps`` random-policy steps of every lane in one kernel launch: the effect of
+        ``fill_actions(buf, action_seed, action_t0 + k); step(buf)`` for k in range(n_steps), bit for bit
+        (the caller loop of examples/cartpole.rs:15-30)."""
+        _check(self._lib, self._lib.gymrs_rollout(self._h, int(n_steps), int(action_seed), int(action_t0)))
+
     def fill_actions(self, actions_dev: int, seed: int, t: int) -> None:
         _check(self._lib, self._lib.gymrs_fill_actions(self._h, C.c_void_p(actions_dev), int(seed), int(t)))
 

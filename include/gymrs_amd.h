@@ -147,6 +147,14 @@ gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host);
  * for Pendulum with GYMRS_TIME_LIMIT (GYMRS_EINVAL). */
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes,
                              uint32_t n_buffers, uint32_t n_steps, int use_graph);
+/* Fused random-policy rollout: exactly the effect of
+ *     for (k = 0; k < n_steps; ++k) { gymrs_fill_actions(e, buf, action_seed, action_t0 + k); gymrs_step(e, buf); }
+ * in ONE kernel launch with the state held in registers (the caller loop of examples/cartpole.rs:15-30 --
+ * `rng.gen_range`, `step`, `reset` on done, `episode reward +=` -- for every lane).  Afterwards the state, the
+ * reward/done/truncated arrays (those of the LAST step), the statistics and the tick are bit-identical to that
+ * loop; the intermediate observations are never materialised, which is why this is a separate entry point and
+ * not what bench.py's headline measures.  VALU-bound instead of HBM-bound. */
+gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0);
 /* Wait for the stream; returns GYMRS_EACTION if any step since the last sync saw an invalid action. */
 gymrs_status gymrs_sync(gymrs_engine* e);
 

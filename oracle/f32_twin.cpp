@@ -260,12 +260,10 @@ uint64_t twin_invalid_count(const twin_engine* e) { return e->n_invalid; }
 void twin_fill_actions(const twin_engine* e, void* actions, uint64_t seed, uint64_t t)
 {
     for (uint64_t i = 0; i < e->n; ++i) {
-        const u32x4 r = draw4(seed, e->gid0 + i, t, kStreamAction);
         if (e->kind == GYMRS_PENDULUM) {
-            static_cast<float*>(actions)[i] = uniform_between(r.v[0], -e->max_torque, e->max_torque);
+            static_cast<float*>(actions)[i] = uniform_between(action_word(seed, e->gid0 + i, t), -e->max_torque, e->max_torque);
         } else {
-            const uint32_t na = e->kind == GYMRS_CARTPOLE ? 2u : 3u;
-            static_cast<uint8_t*>(actions)[i] = (uint8_t)(((uint64_t)r.v[0] * na) >> 32);
+            static_cast<uint8_t*>(actions)[i] = action_discrete(seed, e->gid0 + i, t, e->kind == GYMRS_CARTPOLE ? 2u : 3u);
         }
     }
 }

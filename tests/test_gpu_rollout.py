@@ -1,0 +1,106 @@
+"""gymrs_rollout (the fused multi-step kernel) against the CPU f32 twin driven step by step
+through fill_actions + step, and against the per-step GPU kernel: bit-exact state, per-step outputs of the
+last step, statistics and tick."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.bindings import TwinEngine
+
+pytestmark = pytest.mark.gpu
+
+A, S, T = 1, 2, 4
+
+
+def assert_same(eng, tw, kind, flags):
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    assert np.array_equal(eng.get_obs().view(np.uint32), tw.get_obs().view(np.uint32))
+    gr, gd, gt = eng.get_step_result()
+    tr, td, tt = tw.get_result()
+    assert np.array_equal(gr.view(np.uint32), tr.view(np.uint32))
+    assert np.array_equal(gd, td)
+    if flags & T:
+        assert np.array_equal(gt, tt)
+    gs, ts = eng.stats(), tw.stats()
+    assert np.array_equal(gs[1:], ts[1:])
+    if kind == 2:
+        assert gs[0] == pytest.approx(ts[0], rel=1e-5)  # f32 partial sums are grouped per wave on the GPU
+    else:
+        assert gs[0] == ts[0]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("flags", [A | S, A | S | T, A, 0, T, A | T])
+@pytest.mark.parametrize("n,vec", [(5000, 4), (777, 8)])
+def test_rollout_equals_fill_actions_plus_step(gymrs, twin, kind, flags, n, vec):
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 17
+    eng = gymrs.BatchedEngine(kind, n, global_env_offset=12345, flags=flags, params=p, lanes_per_thread=vec)
+    tw = TwinEngine(twin, kind, n, p, flags=flags, gid0=12345)
+    eng.reset(seed=3)
+    tw.reset(3)
+    t = 0
+    for steps, t0 in ((1, 0), (7, 1), (40, 8), (3, 1001)):  # unaligned starts, chunk remainders, two time limits
+        eng.rollout(steps, action_seed=6, action_t0=t0)
+        for k in range(steps):
+            tw.step(tw.fill_actions(6, t0 + k))
+        t += steps
+        assert_same(eng, tw, kind, flags)
+        assert eng.tick()[0] == t + 1
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_rollout_interleaves_with_per_step_kernel(gymrs, twin, kind):
+    """rollout -> step -> rollout on the same engine: both kernels keep the shared bookkeeping (ep_start,
+    statistics slots, Pendulum's uniform episode clock) in the same state."""
+    n, flags = 6001, A | S | T
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 11
+    eng = gymrs.BatchedEngine(kind, n, flags=flags, params=p)
+    tw = TwinEngine(twin, kind, n, p, flags=flags)
+    eng.reset(seed=8)
+    tw.reset(8)
+    buf = torch.empty(n, dtype=torch.float32 if kind == 2 else torch.uint8, device="cuda:0")
+    t = 0
+    for phase in range(3):
+        eng.rollout(9, action_seed=2, action_t0=t)
+        for k in range(9):
+            tw.step(tw.fill_actions(2, t + k))
+        t += 9
+        for k in range(5):
+            eng.fill_actions(buf.data_ptr(), seed=2, t=t + k)
+            eng.step(buf.data_ptr())
+            tw.step(tw.fill_actions(2, t + k))
+        t += 5
+        assert_same(eng, tw, kind, flags)
+    eng.close()
+
+
+def test_rollout_matches_per_step_gpu_at_full_size(gymrs):
+    """BASELINE configs[1] size: 2^20 CartPole lanes, 64 steps, fused vs per-step kernel on the GPU."""
+    n, steps = 1 << 20, 64
+    flags = A | S
+    a = gymrs.BatchedEngine(0, n, flags=flags)
+    b = gymrs.BatchedEngine(0, n, flags=flags)
+    a.reset(seed=0)
+    b.reset(seed=0)
+    a.rollout(steps, action_seed=1, action_t0=0)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    for k in range(steps):
+        b.fill_actions(buf.data_ptr(), seed=1, t=k)
+        b.step(buf.data_ptr())
+    assert np.array_equal(a.get_state().view(np.uint32), b.get_state().view(np.uint32))
+    assert np.array_equal(a.stats(), b.stats())
+    sa = a.stats()
+    assert sa[3] == n * steps and 15 < sa[1] / sa[2] < 30  # random-policy CartPole episodes last ~22 steps
+    a.close()
+    b.close()
+
+
+def test_rollout_zero_steps_is_a_no_op(gymrs):
+    with gymrs.BatchedEngine(0, 100, flags=A | S) as eng:
+        eng.reset(seed=1)
+        before = eng.get_state()
+        eng.rollout(0, action_seed=1)
+        assert np.array_equal(before, eng.get_state()) and eng.tick()[0] == 1
