@@ -46,6 +46,10 @@ SIGNATURES = {
     "gymrs_comm_unique_id": (C.c_int, [C.c_void_p]),
     "gymrs_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "gymrs_allreduce_stats": (C.c_int, [C.c_void_p, f64p]),
+    "gymrs_engine_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gymrs_snapshot_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "gymrs_snapshot_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "gymrs_snapshot_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "gymrs_rollout": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "gymrs_fill_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gymrs_get_tick": (C.c_int, [C.c_void_p, u64p, u64p]),

@@ -78,6 +78,7 @@ struct gymrs_engine {
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
     void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
+    size_t pool_bytes = 0;
     int vec = 4; // lanes per work-item
     int nt_mode = 0; // 0 = automatic, 1 = always non-temporal, 2 = never
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
@@ -436,6 +437,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
             return fail(perr == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("hipMalloc: ") + hipGetErrorString(perr));
         }
         e->pool = pool;
+        e->pool_bytes = off + 256;
         char* b = static_cast<char*>(pool);
         for (int j = 0; j < e->state_dim; ++j) e->s[j] = reinterpret_cast<float*>(b + at_s[j]);
         if (pend) {
@@ -830,6 +832,186 @@ gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t cou
     if (done) HIP_TRY(hipMemcpyAsync(done, e->done + first, count, hipMemcpyDeviceToHost, e->stream));
     if (truncated) HIP_TRY(hipMemcpyAsync(truncated, e->truncated + first, count, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// `Env: Clone + Serialize` (core.rs:25).  Clone = a second engine with a deep copy of everything a step can
+// observe (lane arrays, episode bookkeeping, statistics, RNG position = seed + tick).  The snapshot is the
+// same content as a host blob; a restored engine continues bit-identically to the uninterrupted run.
+extern "C++" {
+namespace {
+struct SnapshotHeader {
+    char magic[8]; // "GYMRSNAP"
+    uint32_t version, kind;
+    uint64_t n, gid0;
+    uint32_t flags, state_dim, epoch, n_stat_blocks, max_steps, has_ret;
+    uint64_t seed, tick, uniform_start;
+    double n_steps_total;
+    float lo[4], hi[4], max_torque;
+    uint32_t consts_bytes;
+    unsigned char consts[96];
+};
+static_assert(sizeof(CartPoleConsts) <= 96 && sizeof(MountainCarConsts) <= 96 && sizeof(PendulumConsts) <= 96, "consts blob too small");
+constexpr uint32_t kSnapshotVersion = 1;
+
+struct Segment {
+    void* dev;
+    size_t bytes;
+};
+// the device arrays of a snapshot, in blob order
+std::vector<Segment> snapshot_segments(const gymrs_engine* e)
+{
+    std::vector<Segment> v;
+    const size_t n = (size_t)e->n;
+    for (int j = 0; j < e->state_dim; ++j) v.push_back({e->s[j], n * 4});
+    if (e->obs_cos) v.push_back({e->obs_cos, n * 4});
+    if (e->obs_sin) v.push_back({e->obs_sin, n * 4});
+    if (e->ep_ret) v.push_back({e->ep_ret, n * 4});
+    v.push_back({e->reward, n * 4});
+    v.push_back({e->done, n});
+    v.push_back({e->truncated, n});
+    v.push_back({e->beyond, n});
+    v.push_back({e->ep_start, n * 4});
+    v.push_back({e->block_stats, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long)});
+    v.push_back({e->stats_base, sizeof(unsigned long long)});
+    v.push_back({e->err, 2 * sizeof(uint32_t)});
+    return v;
+}
+size_t consts_size(gymrs_env_kind k)
+{
+    return k == GYMRS_CARTPOLE ? sizeof(CartPoleConsts) : (k == GYMRS_MOUNTAIN_CAR ? sizeof(MountainCarConsts) : sizeof(PendulumConsts));
+}
+void drop_graph(gymrs_engine* e)
+{
+    if (e->graph_exec) {
+        (void)hipGraphExecDestroy(e->graph_exec);
+        e->graph_exec = nullptr;
+    }
+}
+// the host-side scalars a step depends on
+void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
+{
+    dst->consts = src->consts;
+    dst->max_torque = src->max_torque;
+    dst->max_steps = src->max_steps;
+    std::memcpy(dst->lo, src->lo, sizeof(dst->lo));
+    std::memcpy(dst->hi, src->hi, sizeof(dst->hi));
+    std::memcpy(dst->dflt_lo, src->dflt_lo, sizeof(dst->dflt_lo));
+    std::memcpy(dst->dflt_hi, src->dflt_hi, sizeof(dst->dflt_hi));
+    dst->epoch = src->epoch;
+    dst->seed = src->seed;
+    dst->tick = src->tick;
+    dst->uniform_start = src->uniform_start;
+    dst->n_steps_total = src->n_steps_total;
+    dst->vec = src->vec;
+    dst->nt_mode = src->nt_mode;
+}
+} // namespace
+} // extern "C++"
+
+gymrs_status gymrs_engine_clone(gymrs_engine* src, gymrs_engine** out)
+{
+    if (!src || !out) return fail(GYMRS_EINVAL, "gymrs_engine_clone: NULL argument");
+    *out = nullptr;
+    gymrs_engine* dst = nullptr;
+    if (gymrs_status st = gymrs_engine_create(src->kind, src->n, src->gid0, src->device, nullptr, src->flags, &dst)) return st;
+    copy_scalars(dst, src);
+    hipError_t err = hipStreamSynchronize(src->stream); // everything queued on the source has happened
+    const std::vector<Segment> from = snapshot_segments(src), to = snapshot_segments(dst);
+    for (size_t i = 0; i < from.size() && err == hipSuccess; ++i)
+        err = hipMemcpyAsync(to[i].dev, from[i].dev, from[i].bytes, hipMemcpyDeviceToDevice, dst->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(dst->stream);
+    if (err != hipSuccess) {
+        gymrs_engine_destroy(dst);
+        return fail(GYMRS_EHIP, std::string("gymrs_engine_clone: ") + hipGetErrorString(err));
+    }
+    *out = dst;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_snapshot_size(gymrs_engine* e, uint64_t* bytes)
+{
+    if (!e || !bytes) return fail(GYMRS_EINVAL, "gymrs_snapshot_size: NULL argument");
+    size_t total = sizeof(SnapshotHeader);
+    for (const Segment& sg : snapshot_segments(e)) total += sg.bytes;
+    *bytes = total;
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes)
+{
+    if (!e || !host_buf) return fail(GYMRS_EINVAL, "gymrs_snapshot_save: NULL argument");
+    uint64_t need = 0;
+    (void)gymrs_snapshot_size(e, &need);
+    if (bytes < need) return fail(GYMRS_EINVAL, "gymrs_snapshot_save: buffer smaller than gymrs_snapshot_size");
+    HIP_TRY(hipSetDevice(e->device));
+    SnapshotHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, "GYMRSNAP", 8);
+    h.version = kSnapshotVersion;
+    h.kind = (uint32_t)e->kind;
+    h.n = e->n;
+    h.gid0 = e->gid0;
+    h.flags = e->flags;
+    h.state_dim = (uint32_t)e->state_dim;
+    h.epoch = e->epoch;
+    h.n_stat_blocks = e->n_stat_blocks;
+    h.max_steps = e->max_steps;
+    h.has_ret = e->ep_ret ? 1u : 0u;
+    h.seed = e->seed;
+    h.tick = e->tick;
+    h.uniform_start = e->uniform_start;
+    h.n_steps_total = e->n_steps_total;
+    std::memcpy(h.lo, e->lo, sizeof(h.lo));
+    std::memcpy(h.hi, e->hi, sizeof(h.hi));
+    h.max_torque = e->max_torque;
+    h.consts_bytes = (uint32_t)consts_size(e->kind);
+    std::memcpy(h.consts, consts_ptr(e), h.consts_bytes);
+    char* p = static_cast<char*>(host_buf);
+    std::memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    for (const Segment& sg : snapshot_segments(e)) {
+        HIP_TRY(hipMemcpyAsync(p, sg.dev, sg.bytes, hipMemcpyDeviceToHost, e->stream));
+        p += sg.bytes;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t bytes)
+{
+    if (!e || !host_buf) return fail(GYMRS_EINVAL, "gymrs_snapshot_load: NULL argument");
+    if (bytes < sizeof(SnapshotHeader)) return fail(GYMRS_EINVAL, "gymrs_snapshot_load: truncated snapshot");
+    SnapshotHeader h;
+    std::memcpy(&h, host_buf, sizeof(h));
+    if (std::memcmp(h.magic, "GYMRSNAP", 8) != 0 || h.version != kSnapshotVersion)
+        return fail(GYMRS_EINVAL, "gymrs_snapshot_load: not a gymrs snapshot of this version");
+    if (h.kind != (uint32_t)e->kind || h.n != e->n || h.flags != e->flags || h.state_dim != (uint32_t)e->state_dim ||
+        h.n_stat_blocks != e->n_stat_blocks || h.has_ret != (e->ep_ret ? 1u : 0u) || h.consts_bytes != consts_size(e->kind))
+        return fail(GYMRS_EINVAL, "gymrs_snapshot_load: snapshot was taken from an engine of another kind / size / flags");
+    uint64_t need = 0;
+    (void)gymrs_snapshot_size(e, &need);
+    if (bytes < need) return fail(GYMRS_EINVAL, "gymrs_snapshot_load: truncated snapshot");
+    HIP_TRY(hipSetDevice(e->device));
+    drop_graph(e); // seed and reset box are baked into a captured graph
+    const char* p = static_cast<const char*>(host_buf) + sizeof(h);
+    for (const Segment& sg : snapshot_segments(e)) {
+        HIP_TRY(hipMemcpyAsync(sg.dev, p, sg.bytes, hipMemcpyHostToDevice, e->stream));
+        p += sg.bytes;
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->gid0 = h.gid0;
+    e->epoch = h.epoch;
+    e->max_steps = h.max_steps;
+    e->seed = h.seed;
+    e->tick = h.tick;
+    e->uniform_start = h.uniform_start;
+    e->n_steps_total = h.n_steps_total;
+    std::memcpy(e->lo, h.lo, sizeof(e->lo));
+    std::memcpy(e->hi, h.hi, sizeof(e->hi));
+    e->max_torque = h.max_torque;
+    std::memcpy(&e->consts, h.consts, h.consts_bytes);
     return GYMRS_OK;
 }
 

@@ -131,6 +131,31 @@ class BatchedEngine:
     def __exit__(self, *exc):
         self.close()
 
+    # -- Clone + Serialize (core.rs:25) ---------------------------------------------------------
+    def clone(self) -> "BatchedEngine":
+        """Deep copy (``Env: Clone``): lane state, episode bookkeeping, statistics, RNG position."""
+        h = C.c_void_p()
+        _check(self._lib, self._lib.gymrs_engine_clone(self._h, C.byref(h)))
+        other = BatchedEngine.__new__(BatchedEngine)
+        other.__dict__.update({k: v for k, v in self.__dict__.items() if k != "_h"})
+        other.params = type(self.params).from_buffer_copy(self.params)
+        other._h = h
+        return other
+
+    def snapshot(self) -> bytes:
+        """Everything a step can observe as an opaque blob (``Env: Serialize``); see ``restore``."""
+        size = C.c_uint64()
+        _check(self._lib, self._lib.gymrs_snapshot_size(self._h, C.byref(size)))
+        buf = (C.c_char * size.value)()
+        _check(self._lib, self._lib.gymrs_snapshot_save(self._h, buf, size.value))
+        return bytes(buf)
+
+    def restore(self, blob: bytes) -> None:
+        """Load a ``snapshot()`` taken from an engine of the same kind, n_envs and flags; stepping then
+        continues bit-identically to the engine the snapshot came from."""
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        _check(self._lib, self._lib.gymrs_snapshot_load(self._h, buf, len(blob)))
+
     # -- stream / tuning ----------------------------------------------------------------------
     @property
     def stream(self) -> int:

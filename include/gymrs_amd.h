@@ -155,6 +155,19 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
  * loop; the intermediate observations are never materialised, which is why this is a separate entry point and
  * not what bench.py's headline measures.  VALU-bound instead of HBM-bound. */
 gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0);
+/* `Env: Clone + Serialize` (core.rs:25; the serde-visible fields of cartpole.rs:51-87 / mountain_car.rs:46-80).
+ * gymrs_engine_clone: a second engine (own stream, same device) with a deep copy of everything a step can observe:
+ * lane state, episode bookkeeping, statistics, physics constants, reset box and the RNG position (seed, tick).
+ * Like the reference's Clone (which drops the GUI handle, screen.rs:66-77) it does not copy the HIP stream binding,
+ * the RCCL communicator or a captured graph.
+ * gymrs_snapshot_*: the same content as an opaque host blob of gymrs_snapshot_size() bytes.  Loading requires an
+ * engine created with the same kind, n_envs and flags (GYMRS_EINVAL otherwise); physics constants, reset box,
+ * global_env_offset, seed and tick come from the snapshot.  A restored or cloned engine continues bit-identically
+ * to the original. */
+gymrs_status gymrs_engine_clone(gymrs_engine* src, gymrs_engine** out);
+gymrs_status gymrs_snapshot_size(gymrs_engine* e, uint64_t* bytes);
+gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes);
+gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t bytes);
 /* Wait for the stream; returns GYMRS_EACTION if any step since the last sync saw an invalid action. */
 gymrs_status gymrs_sync(gymrs_engine* e);
 

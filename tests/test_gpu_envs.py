@@ -4,6 +4,8 @@
 behind it.  Expected values: tests/golden."""
 import math
 
+import numpy as np
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -120,3 +122,49 @@ def test_cpp_trait_mirror(tmp_path):
                    check=True, capture_output=True, text=True)
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "CPP_MIRROR_OK" in res.stdout, res.stdout + res.stderr
+
+
+# ---- Clone + Serialize (core.rs:25) ------------------------------------------------------------
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_clone_and_snapshot_continue_bit_identically(gymrs, kind):
+    """A clone, and an engine restored from a snapshot, continue exactly like the original: same states,
+    same auto-reset draws (RNG position = seed + tick), same statistics."""
+    n = 10_007
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | gymrs.TIME_LIMIT
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 25
+    if kind == 0:
+        p.gravity = 9.9  # non-default constants travel with the snapshot
+    a = gymrs.BatchedEngine(kind, n, global_env_offset=77, flags=flags, params=p)
+    a.reset(seed=31, options=None)
+    a.rollout(30, action_seed=5, action_t0=0)
+    blob = a.snapshot()
+    b = a.clone()
+    c = gymrs.BatchedEngine(kind, n, flags=flags)  # default constants, other shard offset: all overwritten
+    c.restore(blob)
+    for eng in (a, b, c):
+        eng.rollout(40, action_seed=5, action_t0=30)
+    ref_state, ref_stats, ref_res = a.get_state(), a.stats(), a.get_step_result()
+    for eng in (b, c):
+        assert np.array_equal(eng.get_state().view(np.uint32), ref_state.view(np.uint32))
+        assert np.array_equal(eng.stats(), ref_stats)
+        for x, y in zip(eng.get_step_result(), ref_res):
+            assert np.array_equal(x, y)
+        assert eng.tick() == a.tick()
+    assert ref_stats[2] > 0
+    for eng in (a, b, c):
+        eng.close()
+
+
+def test_snapshot_rejects_a_mismatched_engine(gymrs):
+    with gymrs.BatchedEngine(0, 100, flags=gymrs.AUTO_RESET) as a, gymrs.BatchedEngine(0, 101, flags=gymrs.AUTO_RESET) as b, \
+            gymrs.BatchedEngine(1, 100, flags=gymrs.AUTO_RESET) as c:
+        a.reset(seed=1)
+        blob = a.snapshot()
+        for other in (b, c):
+            with pytest.raises(gymrs.GymrsError):
+                other.restore(blob)
+        with pytest.raises(gymrs.GymrsError):
+            a.restore(blob[:64])
+        with pytest.raises(gymrs.GymrsError):
+            a.restore(b"NOTASNAP" + blob[8:])
