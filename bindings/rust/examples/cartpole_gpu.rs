@@ -1,0 +1,37 @@
+//! The caller loop of gym-rs' `examples/cartpole.rs`, twice: through the single-env drop-in, and as the
+//! same loop for a million envs at once on the GPU (one fused launch).
+use gym_rs::core::Env;
+use gym_rs::utils::renderer::RenderMode;
+use gym_rs_amd::cartpole::CartPoleEnv;
+use gym_rs_amd::engine::{Engine, Kind};
+use gym_rs_amd::ffi::{CartPoleParams, GYMRS_AUTO_RESET, GYMRS_TRACK_STATS};
+use rand::{thread_rng, Rng};
+
+fn main() {
+    // 1. source-compatible single env
+    let mut env = CartPoleEnv::new(RenderMode::None);
+    env.reset(Some(0), false, None);
+    let mut rng = thread_rng();
+    let mut episode_return = 0.0;
+    for _ in 0..475 {
+        let action: usize = rng.gen_range(0..=1);
+        let step = env.step(action);
+        episode_return += step.reward.into_inner();
+        if step.done {
+            break;
+        }
+    }
+    println!("single env: episode return {episode_return}");
+
+    // 2. the same random-policy loop for 2^20 envs, 1000 steps each, auto-reset on done
+    let mut batch = Engine::new::<CartPoleParams>(Kind::CartPole, 1 << 20, 0, 0, None, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS);
+    batch.reset(Some(0), None);
+    batch.rollout(1000, 1, 0);
+    batch.sync();
+    let [sum_return, sum_length, n_episodes, n_steps] = batch.stats();
+    println!(
+        "batched: {n_steps} env-steps, {n_episodes} episodes, mean return {:.2}, mean length {:.2}",
+        sum_return / n_episodes,
+        sum_length / n_episodes
+    );
+}

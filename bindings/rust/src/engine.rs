@@ -1,0 +1,179 @@
+//! Safe RAII wrapper of one `gymrs_engine` (one shard of lanes on one GPU, driven by one thread: `&mut self`).
+use crate::ffi;
+use std::ffi::CStr;
+use std::os::raw::{c_int, c_void};
+
+/// Which env the lanes of an engine are.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Kind {
+    /// `CartPoleEnv` (cartpole.rs)
+    CartPole,
+    /// `MountainCarEnv` (mountain_car.rs)
+    MountainCar,
+}
+
+impl Kind {
+    fn raw(self) -> c_int {
+        match self {
+            Kind::CartPole => ffi::GYMRS_CARTPOLE,
+            Kind::MountainCar => ffi::GYMRS_MOUNTAIN_CAR,
+        }
+    }
+    /// Number of f32 state components per lane.
+    pub fn state_dim(self) -> usize {
+        match self {
+            Kind::CartPole => 4,
+            Kind::MountainCar => 2,
+        }
+    }
+}
+
+/// The reference has no `Result`s: every failure is a panic (cartpole.rs:402-406, screen.rs:184-203).
+/// So is every non-zero status of the C ABI here.
+fn check(status: c_int) {
+    if status != ffi::GYMRS_OK {
+        let msg = unsafe { CStr::from_ptr(ffi::gymrs_last_error()) }.to_string_lossy().into_owned();
+        panic!("gymrs_amd: status {status}: {msg}");
+    }
+}
+
+/// Result of one step of one lane, as host values.
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub struct LaneResult {
+    /// reward of the step
+    pub reward: f32,
+    /// the episode terminated
+    pub done: bool,
+    /// the episode hit the time limit (only with `GYMRS_TIME_LIMIT`)
+    pub truncated: bool,
+}
+
+/// Owns the engine handle; dropping it releases the device memory (`Env::close`, core.rs:56).
+#[derive(Debug)]
+pub struct Engine {
+    raw: *mut ffi::GymrsEngine,
+    kind: Kind,
+    n: u64,
+}
+
+impl Engine {
+    /// `gymrs_engine_create`.  `params` must be the params struct matching `kind` (or `None` for the defaults).
+    pub fn new<P>(kind: Kind, n_envs: u64, global_env_offset: u64, device: i32, params: Option<&P>, flags: u32) -> Self {
+        let mut raw = std::ptr::null_mut();
+        let p = params.map_or(std::ptr::null(), |p| p as *const P as *const c_void);
+        check(unsafe { ffi::gymrs_engine_create(kind.raw(), n_envs, global_env_offset, device, p, flags, &mut raw) });
+        Engine { raw, kind, n: n_envs }
+    }
+
+    /// Number of lanes.
+    pub fn len(&self) -> u64 {
+        self.n
+    }
+
+    /// `true` for an engine without lanes.
+    pub fn is_empty(&self) -> bool {
+        self.n == 0
+    }
+
+    /// `Env::reset` for every lane; returns the seed used (seeding.rs:21-26 echoes it the same way).
+    pub fn reset(&mut self, seed: Option<u64>, bounds_low_high: Option<&[f32]>) -> u64 {
+        if let Some(b) = bounds_low_high {
+            assert_eq!(b.len(), 2 * self.kind.state_dim(), "bounds = state_dim lows then state_dim highs");
+        }
+        let mut used = 0u64;
+        check(unsafe {
+            ffi::gymrs_reset(
+                self.raw,
+                seed.is_some() as c_int,
+                seed.unwrap_or(0),
+                bounds_low_high.map_or(std::ptr::null(), |b| b.as_ptr()),
+                &mut used,
+            )
+        });
+        used
+    }
+
+    /// One `Env::step` of every lane with host actions (one u8 per lane), then wait for it.
+    pub fn step_host(&mut self, actions: &[u8]) {
+        assert_eq!(actions.len() as u64, self.n);
+        check(unsafe { ffi::gymrs_step_host(self.raw, actions.as_ptr() as *const c_void) });
+        check(unsafe { ffi::gymrs_sync(self.raw) });
+    }
+
+    /// One asynchronous `Env::step` with a device-resident action buffer (one u8 per lane).
+    ///
+    /// # Safety
+    /// `actions_dev` must be a device address of at least `len()` bytes that stays valid until `sync()`.
+    pub unsafe fn step_device(&mut self, actions_dev: *const c_void) {
+        check(ffi::gymrs_step(self.raw, actions_dev));
+    }
+
+    /// `n_steps` random-policy steps fused into one launch (the loop of examples/cartpole.rs:15-30 per lane).
+    pub fn rollout(&mut self, n_steps: u32, action_seed: u64, action_t0: u64) {
+        check(unsafe { ffi::gymrs_rollout(self.raw, n_steps, action_seed, action_t0) });
+    }
+
+    /// Wait for everything queued on the engine's stream.
+    pub fn sync(&mut self) {
+        check(unsafe { ffi::gymrs_sync(self.raw) });
+    }
+
+    /// State of lanes `first..first+count`, component-major (`[component][lane]`).
+    pub fn state(&mut self, first: u64, count: u64) -> Vec<f32> {
+        let mut out = vec![0f32; self.kind.state_dim() * count as usize];
+        check(unsafe { ffi::gymrs_get_state(self.raw, first, count, out.as_mut_ptr()) });
+        out
+    }
+
+    /// Overwrite the state of lanes `first..first+count` (like assigning the pub `state` field).
+    pub fn set_state(&mut self, first: u64, count: u64, component_major: &[f32]) {
+        assert_eq!(component_major.len(), self.kind.state_dim() * count as usize);
+        check(unsafe { ffi::gymrs_set_state(self.raw, first, count, component_major.as_ptr()) });
+    }
+
+    /// Reward / done / truncated of the last step of one lane.
+    pub fn lane_result(&mut self, lane: u64) -> LaneResult {
+        let (mut reward, mut done, mut truncated) = (0f32, 0u8, 0u8);
+        check(unsafe { ffi::gymrs_get_step_result(self.raw, lane, 1, &mut reward, &mut done, &mut truncated) });
+        LaneResult { reward, done: done != 0, truncated: truncated != 0 }
+    }
+
+    /// `[sum_return, sum_length, n_episodes, n_steps]` since the last reset / clear.
+    pub fn stats(&mut self) -> [f64; 4] {
+        let mut out = [0f64; 4];
+        check(unsafe { ffi::gymrs_stats(self.raw, out.as_mut_ptr()) });
+        out
+    }
+
+    /// Opaque blob holding everything a step can observe (`Serialize`).
+    pub fn snapshot(&mut self) -> Vec<u8> {
+        let mut bytes = 0u64;
+        check(unsafe { ffi::gymrs_snapshot_size(self.raw, &mut bytes) });
+        let mut buf = vec![0u8; bytes as usize];
+        check(unsafe { ffi::gymrs_snapshot_save(self.raw, buf.as_mut_ptr() as *mut c_void, bytes) });
+        buf
+    }
+
+    /// Load a `snapshot()` of an engine with the same kind, lane count and flags.
+    pub fn restore(&mut self, blob: &[u8]) {
+        check(unsafe { ffi::gymrs_snapshot_load(self.raw, blob.as_ptr() as *const c_void, blob.len() as u64) });
+    }
+}
+
+impl Clone for Engine {
+    /// Deep copy on the device (`gymrs_engine_clone`): state, episode bookkeeping, RNG position.
+    fn clone(&self) -> Self {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe { ffi::gymrs_engine_clone(self.raw, &mut raw) });
+        Engine { raw, kind: self.kind, n: self.n }
+    }
+}
+
+impl Drop for Engine {
+    fn drop(&mut self) {
+        if !self.raw.is_null() {
+            unsafe { ffi::gymrs_engine_destroy(self.raw) };
+            self.raw = std::ptr::null_mut();
+        }
+    }
+}

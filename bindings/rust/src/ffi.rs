@@ -1,0 +1,96 @@
+//! Raw declarations of `include/gymrs_amd.h` (ABI version 1).  Field order and types follow the header.
+#![allow(missing_docs)]
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct GymrsEngine {
+    _opaque: [u8; 0],
+}
+
+pub const GYMRS_OK: c_int = 0;
+pub const GYMRS_EACTION: c_int = 5;
+
+pub const GYMRS_CARTPOLE: c_int = 0;
+pub const GYMRS_MOUNTAIN_CAR: c_int = 1;
+pub const GYMRS_PENDULUM: c_int = 2;
+
+pub const GYMRS_AUTO_RESET: u32 = 1;
+pub const GYMRS_TRACK_STATS: u32 = 2;
+pub const GYMRS_TIME_LIMIT: u32 = 4;
+
+/// `gymrs_cartpole_params`: the pub physics fields of `CartPoleEnv` (cartpole.rs:53-82), f64 like the reference.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub struct CartPoleParams {
+    pub gravity: f64,
+    pub masscart: f64,
+    pub masspole: f64,
+    pub length: f64,
+    pub force_mag: f64,
+    pub tau: f64,
+    pub theta_threshold_radians: f64,
+    pub x_threshold: f64,
+    /// 0 = Euler, 1 = semi-implicit (`KinematicsIntegrator`, cartpole.rs:380-387)
+    pub kinematics_integrator: i32,
+    pub max_episode_steps: u32,
+}
+
+/// `gymrs_mountain_car_params`: the pub physics fields of `MountainCarEnv` (mountain_car.rs:49-77).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq)]
+pub struct MountainCarParams {
+    pub min_position: f64,
+    pub max_position: f64,
+    pub max_speed: f64,
+    pub goal_position: f64,
+    pub goal_velocity: f64,
+    pub force: f64,
+    pub gravity: f64,
+    pub max_episode_steps: u32,
+    pub _pad: u32,
+}
+
+extern "C" {
+    pub fn gymrs_abi_version() -> c_int;
+    pub fn gymrs_last_error() -> *const c_char;
+    pub fn gymrs_default_params(kind: c_int, params: *mut c_void) -> c_int;
+    pub fn gymrs_observation_space(kind: c_int, params: *const c_void, low: *mut f64, high: *mut f64, dim: *mut c_int) -> c_int;
+    pub fn gymrs_engine_create(
+        kind: c_int,
+        n_envs: u64,
+        global_env_offset: u64,
+        device: c_int,
+        params: *const c_void,
+        flags: u32,
+        out: *mut *mut GymrsEngine,
+    ) -> c_int;
+    pub fn gymrs_engine_destroy(e: *mut GymrsEngine) -> c_int;
+    pub fn gymrs_engine_clone(src: *mut GymrsEngine, out: *mut *mut GymrsEngine) -> c_int;
+    pub fn gymrs_reset(e: *mut GymrsEngine, has_seed: c_int, seed: u64, bounds_low_high: *const f32, seed_used: *mut u64) -> c_int;
+    pub fn gymrs_step(e: *mut GymrsEngine, actions_dev: *const c_void) -> c_int;
+    pub fn gymrs_step_host(e: *mut GymrsEngine, actions_host: *const c_void) -> c_int;
+    pub fn gymrs_step_many(
+        e: *mut GymrsEngine,
+        actions_dev: *const c_void,
+        stride_bytes: u64,
+        n_buffers: u32,
+        n_steps: u32,
+        use_graph: c_int,
+    ) -> c_int;
+    pub fn gymrs_rollout(e: *mut GymrsEngine, n_steps: u32, action_seed: u64, action_t0: u64) -> c_int;
+    pub fn gymrs_sync(e: *mut GymrsEngine) -> c_int;
+    pub fn gymrs_get_state(e: *mut GymrsEngine, first: u64, count: u64, host_out: *mut f32) -> c_int;
+    pub fn gymrs_set_state(e: *mut GymrsEngine, first: u64, count: u64, host_in: *const f32) -> c_int;
+    pub fn gymrs_get_step_result(
+        e: *mut GymrsEngine,
+        first: u64,
+        count: u64,
+        reward: *mut f32,
+        done: *mut u8,
+        truncated: *mut u8,
+    ) -> c_int;
+    pub fn gymrs_stats(e: *mut GymrsEngine, out4: *mut f64) -> c_int;
+    pub fn gymrs_snapshot_size(e: *mut GymrsEngine, bytes: *mut u64) -> c_int;
+    pub fn gymrs_snapshot_save(e: *mut GymrsEngine, host_buf: *mut c_void, bytes: u64) -> c_int;
+    pub fn gymrs_snapshot_load(e: *mut GymrsEngine, host_buf: *const c_void, bytes: u64) -> c_int;
+}
