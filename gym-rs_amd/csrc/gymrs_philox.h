@@ -24,6 +24,16 @@ struct u32x4 {
 constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
 constexpr uint32_t kPhiloxW0 = 0x9E3779B9u, kPhiloxW1 = 0xBB67AE85u;
 
+// a ^ b ^ c: one v_bitop3_b32 on gfx950 (the compiler leaves two v_xor_b32 here on its own)
+GYMRS_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 GYMRS_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
 #if defined(__HIPCC__)
@@ -32,8 +42,8 @@ GYMRS_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
     for (int round = 0; round < 10; ++round) {
         uint64_t p0 = (uint64_t)kPhiloxM0 * c0;
         uint64_t p1 = (uint64_t)kPhiloxM1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
