@@ -34,7 +34,7 @@ ENVS = {
     # name: (kind, default lanes per GPU, algorithmic bytes per env-step, workload label)
     "cartpole": (0, 1 << 20, 38, "CartPole-v1 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
     "mountain_car": (1, 1 << 20, 22, "MountainCar-v0 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
-    "pendulum": (2, 1 << 22, 37, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, 200-step time limit"),
+    "pendulum": (2, 1 << 22, 37, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, auto-reset, 200-step time limit, random policy"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 
@@ -69,7 +69,6 @@ def main() -> int:
     ap.add_argument("--n-envs", type=int, default=0, help="lanes per GPU (default: the BASELINE config)")
     ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4, 8, 16); 0 = engine default")
     ap.add_argument("--nt", type=int, default=0, help="memory hint: 0 auto, 1 always non-temporal, 2 never")
-    ap.add_argument("--stats", action="store_true", help="pendulum: also track episode returns (dense accumulator)")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
     ap.add_argument("--rollout", type=int, default=0, metavar="R",
@@ -105,9 +104,7 @@ def main() -> int:
     n = args.n_envs or n_default
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
     if args.env == "pendulum":
-        # It never terminates: episodes end by the 200-step time limit only.  Return tracking needs a dense
-        # per-lane accumulator for this env (+8 B per lane-step), so it is off unless --stats is given.
-        flags = gymrs.AUTO_RESET | gymrs.TIME_LIMIT | (gymrs.TRACK_STATS if args.stats else 0)
+        flags |= gymrs.TIME_LIMIT  # it never terminates: episodes end by the 200-step time limit only
     eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags,
                               lanes_per_thread=args.vec or None)
     if args.nt:

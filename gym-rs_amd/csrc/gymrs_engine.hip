@@ -74,7 +74,8 @@ struct gymrs_engine {
     uint8_t* truncated = nullptr;
     uint8_t* beyond = nullptr;
     uint32_t* ep_start = nullptr;
-    float* ep_ret = nullptr;
+    double* wave_open = nullptr; // per-wavefront sum of the rewards of the open episodes (Pendulum + TRACK_STATS)
+    int open_vec = 0;            // lanes per work-item of the launch that last updated wave_open (0 = none yet)
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
     void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
@@ -148,7 +149,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.truncated = e->truncated;
     a.beyond = e->beyond;
     a.ep_start = e->ep_start;
-    a.ep_ret = e->ep_ret;
+    a.wave_open = e->wave_open;
     a.block_stats = e->block_stats;
     a.err = e->err;
     a.n = e->n;
@@ -315,6 +316,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
+    (void)hipFree(e->wave_open);
     (void)hipFree(e->err);
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     (void)hipFree(e->tick_dev);
@@ -420,13 +422,12 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
             off = (at + bytes + 255) & ~(size_t)255;
             return at;
         };
-        size_t at_s[4] = {0, 0, 0, 0}, at_cos = 0, at_sin = 0, at_ret = 0;
+        size_t at_s[4] = {0, 0, 0, 0}, at_cos = 0, at_sin = 0;
         for (int j = 0; j < e->state_dim; ++j) at_s[j] = place(npad * 4);
         const bool pend = kind == GYMRS_PENDULUM;
         if (pend) {
             at_cos = place(npad * 4);
             at_sin = place(npad * 4);
-            if (flags & GYMRS_TRACK_STATS) at_ret = place(npad * 4);
         }
         const size_t at_reward = place(npad * 4), at_done = place(npad), at_trunc = place(npad), at_beyond = place(npad),
                      at_start = place(npad * 4);
@@ -443,7 +444,6 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
         if (pend) {
             e->obs_cos = reinterpret_cast<float*>(b + at_cos);
             e->obs_sin = reinterpret_cast<float*>(b + at_sin);
-            if (flags & GYMRS_TRACK_STATS) e->ep_ret = reinterpret_cast<float*>(b + at_ret);
         }
         e->reward = reinterpret_cast<float*>(b + at_reward);
         e->done = reinterpret_cast<uint8_t*>(b + at_done);
@@ -453,6 +453,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     }
     e->n_stat_blocks = step_grid(n_envs, 4) * (kBlock / 64); // one statistics slot per wavefront (most waves at vec = 4)
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
+    chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
     chk(dev_alloc(&e->stats_acc, 3));
@@ -563,7 +564,6 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     a.truncated = e->truncated;
     a.beyond = e->beyond;
     a.ep_start = e->ep_start;
-    a.ep_ret = e->ep_ret;
     a.n = e->n;
     a.gid0 = e->gid0;
     a.seed = e->seed;
@@ -575,8 +575,21 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
     // a reset discards the open episodes and starts the statistics afresh
     HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
+    e->open_vec = 0;
     HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
     e->n_steps_total = 0;
+    return GYMRS_OK;
+}
+
+// Pendulum's open-episode reward sums live in per-wavefront slots whose lane coverage depends on the lanes per
+// work-item of the launch: when that changes, gather them into slot 0 (every launch shape has a wave 0) so that
+// no slot the new shape never visits keeps a stranded partial sum.
+static gymrs_status prepare_open_sums(gymrs_engine* e, int vec)
+{
+    if (e->kind != GYMRS_PENDULUM || (e->flags & (GYMRS_TRACK_STATS | GYMRS_AUTO_RESET)) != (GYMRS_TRACK_STATS | GYMRS_AUTO_RESET)) return GYMRS_OK;
+    if (e->open_vec != 0 && e->open_vec != vec) HIP_TRY(launch_fold_open(e->wave_open, e->n_stat_blocks, e->stream));
+    e->open_vec = vec;
     return GYMRS_OK;
 }
 
@@ -584,6 +597,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
 {
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = prepare_open_sums(e, e->vec)) return st;
     StepArgs a = step_args(e, actions_dev);
     HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
     e->tick += 1;
@@ -608,6 +622,7 @@ gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_se
     r.n_actions = e->kind == GYMRS_CARTPOLE ? 2u : 3u;
     r.max_torque = e->max_torque;
     const int vec = e->vec == 8 ? 8 : 4;
+    if (gymrs_status st = prepare_open_sums(e, vec)) return st;
     HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
     for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
         e->tick += 1;
@@ -672,6 +687,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step_many: NULL argument");
     if (n_buffers == 0) return fail(GYMRS_EINVAL, "gymrs_step_many: n_buffers must be > 0");
     HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = prepare_open_sums(e, e->vec)) return st;
     const char* base = static_cast<const char*>(actions_dev);
     uint32_t done = 0;
     // Graph replay pays when the step kernel is shorter than a host launch (~3 us: small batches).  The
@@ -845,7 +861,7 @@ struct SnapshotHeader {
     char magic[8]; // "GYMRSNAP"
     uint32_t version, kind;
     uint64_t n, gid0;
-    uint32_t flags, state_dim, epoch, n_stat_blocks, max_steps, has_ret;
+    uint32_t flags, state_dim, epoch, n_stat_blocks, max_steps, has_ret; // has_ret: now the open_vec of the engine
     uint64_t seed, tick, uniform_start;
     double n_steps_total;
     float lo[4], hi[4], max_torque;
@@ -853,7 +869,7 @@ struct SnapshotHeader {
     unsigned char consts[96];
 };
 static_assert(sizeof(CartPoleConsts) <= 96 && sizeof(MountainCarConsts) <= 96 && sizeof(PendulumConsts) <= 96, "consts blob too small");
-constexpr uint32_t kSnapshotVersion = 1;
+constexpr uint32_t kSnapshotVersion = 2;
 
 struct Segment {
     void* dev;
@@ -867,13 +883,13 @@ std::vector<Segment> snapshot_segments(const gymrs_engine* e)
     for (int j = 0; j < e->state_dim; ++j) v.push_back({e->s[j], n * 4});
     if (e->obs_cos) v.push_back({e->obs_cos, n * 4});
     if (e->obs_sin) v.push_back({e->obs_sin, n * 4});
-    if (e->ep_ret) v.push_back({e->ep_ret, n * 4});
     v.push_back({e->reward, n * 4});
     v.push_back({e->done, n});
     v.push_back({e->truncated, n});
     v.push_back({e->beyond, n});
     v.push_back({e->ep_start, n * 4});
     v.push_back({e->block_stats, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long)});
+    v.push_back({e->wave_open, (size_t)e->n_stat_blocks * sizeof(double)});
     v.push_back({e->stats_base, sizeof(unsigned long long)});
     v.push_back({e->err, 2 * sizeof(uint32_t)});
     return v;
@@ -906,6 +922,7 @@ void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
     dst->n_steps_total = src->n_steps_total;
     dst->vec = src->vec;
     dst->nt_mode = src->nt_mode;
+    dst->open_vec = src->open_vec;
 }
 } // namespace
 } // extern "C++"
@@ -958,7 +975,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
     h.epoch = e->epoch;
     h.n_stat_blocks = e->n_stat_blocks;
     h.max_steps = e->max_steps;
-    h.has_ret = e->ep_ret ? 1u : 0u;
+    h.has_ret = (uint32_t)e->open_vec; // lanes per work-item the open-episode sums were last updated with
     h.seed = e->seed;
     h.tick = e->tick;
     h.uniform_start = e->uniform_start;
@@ -988,7 +1005,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     if (std::memcmp(h.magic, "GYMRSNAP", 8) != 0 || h.version != kSnapshotVersion)
         return fail(GYMRS_EINVAL, "gymrs_snapshot_load: not a gymrs snapshot of this version");
     if (h.kind != (uint32_t)e->kind || h.n != e->n || h.flags != e->flags || h.state_dim != (uint32_t)e->state_dim ||
-        h.n_stat_blocks != e->n_stat_blocks || h.has_ret != (e->ep_ret ? 1u : 0u) || h.consts_bytes != consts_size(e->kind))
+        h.n_stat_blocks != e->n_stat_blocks || h.consts_bytes != consts_size(e->kind))
         return fail(GYMRS_EINVAL, "gymrs_snapshot_load: snapshot was taken from an engine of another kind / size / flags");
     uint64_t need = 0;
     (void)gymrs_snapshot_size(e, &need);
@@ -1011,6 +1028,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     std::memcpy(e->lo, h.lo, sizeof(e->lo));
     std::memcpy(e->hi, h.hi, sizeof(e->hi));
     e->max_torque = h.max_torque;
+    e->open_vec = (int)h.has_ret;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
     return GYMRS_OK;
 }

@@ -21,7 +21,7 @@ struct StepArgs {
     uint8_t* truncated; // written only with GYMRS_TIME_LIMIT
     uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
     uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
-    float* ep_ret;      // Pendulum with GYMRS_TRACK_STATS: running episode return
+    double* wave_open;  // [n_waves] Pendulum with GYMRS_TRACK_STATS: per-wavefront sum of the rewards of the open episodes
     unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1
     uint64_t n;         // lanes in this engine
@@ -53,7 +53,6 @@ struct ResetArgs {
     uint8_t* truncated;
     uint8_t* beyond;
     uint32_t* ep_start;
-    float* ep_ret;
     uint64_t n, gid0, seed, tick;
     SampleBox box;
 };
@@ -70,6 +69,8 @@ hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepA
 hipError_t launch_rollout(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const RolloutArgs& r,
                           const void* consts, hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
+// wave_open[0] += sum of the others, others = 0 (before a launch whose lanes-per-wave differs from the last one's)
+hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream);
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);

@@ -51,16 +51,21 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
     // path holds no atomic and nothing waits on the statistics.  (Launches are stream-ordered and a slot
     // has exactly one writer per launch.)
     unsigned long long old_resets = 0;
-    double old_ret = 0.0;
+    double old_ret = 0.0, open = 0.0;
+    const size_t wave_slot = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (STATS) {
-        const unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2;
+        const unsigned long long* bs = a.block_stats + wave_slot * 2;
         old_resets = bs[0];
-        if (!Env::kConstReward) old_ret = reinterpret_cast<const double*>(bs)[1];
+        if (!Env::kConstReward) {
+            old_ret = reinterpret_cast<const double*>(bs)[1];
+            open = a.wave_open[wave_slot];
+        }
     }
     GYMRS_STAMP(1);
     StepOut<VEC> out;
-    advance_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret, out);
+    advance_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret, open, out);
     store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out);
+    if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
     GYMRS_STAMP(6);
 }
 
@@ -116,7 +121,6 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
     a.truncated[lane] = 0;
     if (Env::kHasBeyond) a.beyond[lane] = 0; // steps_beyond_terminated = None, cartpole.rs:504
     a.ep_start[lane] = (uint32_t)(a.tick + 1); // = the epoch the statistics are measured from
-    if (a.ep_ret) a.ep_ret[lane] = 0.0f;
 }
 
 // Random-policy actions (examples/cartpole.rs:19 `rng.gen_range(0..=1)`), Philox stream 1.
@@ -246,6 +250,22 @@ hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepA
     case GYMRS_PENDULUM: return launch_vec<PendulumT>(vec, flags, a, consts, stream);
     default: return hipErrorInvalidValue;
     }
+}
+
+__global__ void fold_open_kernel(double* wave_open, uint32_t n_slots)
+{
+    double sum = 0.0;
+    for (uint32_t i = 0; i < n_slots; ++i) {
+        sum += wave_open[i];
+        wave_open[i] = 0.0;
+    }
+    wave_open[0] = sum;
+}
+
+hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fold_open_kernel, dim3(1), dim3(1), 0, stream, wave_open, n_slots);
+    return hipGetLastError();
 }
 
 __global__ void tick_advance_kernel(unsigned long long* tick_dev, unsigned long long by) { *tick_dev += by; }

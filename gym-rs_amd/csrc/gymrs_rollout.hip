@@ -21,11 +21,15 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
     R d;
     load_tile<Env, VEC, FLAGS, FULL, true>(a, base, d);
     unsigned long long resets = 0;
-    double ret = 0.0;
-    unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2;
+    double ret = 0.0, open = 0.0;
+    const size_t wave_slot = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    unsigned long long* bs = a.block_stats + wave_slot * 2;
     if (R::STATS) {
         resets = bs[0];
-        if (!Env::kConstReward) ret = reinterpret_cast<const double*>(bs)[1];
+        if (!Env::kConstReward) {
+            ret = reinterpret_cast<const double*>(bs)[1];
+            open = a.wave_open[wave_slot];
+        }
     }
     StepOut<VEC> out;
     constexpr bool kDiscrete = sizeof(Action) == 1;
@@ -66,12 +70,15 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
             a.truncate_all = (a.tick + 1 - ustart >= c.max_steps) ? 1u : 0u;
             if (a.truncate_all && R::AUTO) ustart = a.tick + 1;
         }
-        advance_tile<Env, VEC, FLAGS, FULL, true>(a, c, base, d, lds, resets, ret, out);
+        advance_tile<Env, VEC, FLAGS, FULL, true>(a, c, base, d, lds, resets, ret, open, out);
     }
     store_tile<Env, VEC, FLAGS, FULL, true>(a, base, d, out);
     if (R::STATS && (threadIdx.x & 63u) == 0) {
         bs[0] = resets;
-        if (!Env::kConstReward) reinterpret_cast<double*>(bs)[1] = ret;
+        if (!Env::kConstReward) {
+            reinterpret_cast<double*>(bs)[1] = ret;
+            a.wave_open[wave_slot] = open;
+        }
     }
 }
 

@@ -20,6 +20,24 @@ namespace gymrs {
 #define GYMRS_STAMP(slot_) do { } while (0)
 #endif
 
+// Sum of `v` over the 64 lanes of the wavefront, returned wave-uniform.  Six DPP adds (quad swaps, row
+// mirrors, row broadcasts -- the cross-lane paths of the VALU itself) instead of six ds_bpermute round trips.
+__device__ __forceinline__ float wave_sum(float v)
+{
+    auto dpp_add = [](float x, auto ctrl, auto row_mask) {
+        const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+        return x + __builtin_bit_cast(float, moved);
+    };
+    using std::integral_constant;
+    v = dpp_add(v, integral_constant<int, 0xb1>{}, integral_constant<int, 0xf>{});  // quad_perm [1,0,3,2]
+    v = dpp_add(v, integral_constant<int, 0x4e>{}, integral_constant<int, 0xf>{});  // quad_perm [2,3,0,1]
+    v = dpp_add(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{}); // row_half_mirror
+    v = dpp_add(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{}); // row_mirror: every lane holds its row's sum
+    v = dpp_add(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{}); // row_bcast:15 into rows 1 and 3
+    v = dpp_add(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{}); // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // ---------------------------------------------------------------------------------------------
 // vector access helpers
 template <class T, int V>
@@ -162,7 +180,6 @@ struct TileRegs {
     Vec<typename Env::Action, VEC> act;
     Vec<uint8_t, VEC> beyond;
     Vec<uint32_t, VEC> ep_start;
-    Vec<float, VEC> ep_ret;
 };
 
 // ROLL = the fused multi-step kernel: actions are generated in registers and ep_start travels densely
@@ -179,11 +196,10 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
     if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, uint8_t(0));
     if (ROLL ? (R::STATS || R::TLIM) : (R::TLIM && !Env::kNeverTerminates))
         d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
-    if (R::STATS && !Env::kConstReward) d.ep_ret = load_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, 0.0f);
 }
 
 // LDS of one workgroup for the auto-reset hand-off: every wavefront uses its own 256-entry segment
-// (list of finished lanes, their fresh states, their finished returns); waves never touch each other's.
+// (list of finished lanes, their fresh states); waves never touch each other's.
 template <class Env, int VEC>
 struct ResetLds {
     static constexpr int kLanes = kBlock * VEC;
@@ -192,7 +208,6 @@ struct ResetLds {
         float v[Env::kState];
     };
     State fresh[kLanes]; // one ds_write/ds_read of 8 or 16 bytes per finished lane
-    float ret[Env::kConstReward ? 1 : kLanes];
 };
 
 // The branch-free physics of the 4 lanes of a work-item in one basic block (V = Env variant).
@@ -224,11 +239,17 @@ struct StepOut {
 // kernel calls it once between load_tile and store_tile; the fused rollout kernel calls it in a loop.
 // `resets`/`ret` are the wave's statistics slot values: the per-step kernel stores the updated slot from
 // here, the rollout kernel (ROLL) keeps accumulating in registers and stores once at the end.
+// `open` (envs with a non-constant reward, i.e. Pendulum) is the wave's sum of the rewards of its OPEN episodes:
+// such an env never terminates, so all lanes share one episode clock, finish together, and the return of the
+// finished episodes of a wave is just that sum -- no per-lane return accumulator in HBM (which cost 8 B per
+// lane-step: 29.6 vs 23.4 us per 2^22-lane step).  The caller loads/stores `open` (StepArgs::wave_open).
 template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false>
 __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
                                              TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC>& lds, unsigned long long& resets,
-                                             double& ret, StepOut<VEC>& out)
+                                             double& ret, double& open, StepOut<VEC>& out)
 {
+    static_assert(Env::kConstReward || Env::kNeverTerminates,
+                  "return tracking assumes a constant reward (return = +-length) or one shared episode clock");
     constexpr int kVec = VEC;
     using R = TileRegs<Env, VEC, FLAGS>;
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
@@ -310,10 +331,15 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             tr[k] = TLIM && stepped && a.truncate_all != 0;
         else
             tr[k] = TLIM && stepped && (tick_next - d.ep_start.v[k]) >= c.max_steps;
-        if (STATS && !Env::kConstReward) d.ep_ret.v[k] += rw[k];
         done.v[k] = dn[k] ? 1 : 0;
         trunc.v[k] = tr[k] ? 1 : 0;
         need_reset[k] = AUTO && (dn[k] || tr[k]);
+    }
+    if (STATS && !Env::kConstReward) { // this step's rewards join the wave's open-episode sum (lanes not stepped have 0)
+        float rs = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) rs += rw[k];
+        open += (double)wave_sum(rs);
     }
 
     // ---- auto-reset: wave __ballot done-mask -> LDS-staged Philox, all inside one wavefront ----
@@ -330,7 +356,6 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             slot[k] = total + rank;
             if (need_reset[k]) {
                 list[slot[k]] = (uint16_t)(lane * kVec + k); // wave-local lane
-                if (STATS && !Env::kConstReward) lds.ret[wave * LPW + slot[k]] = d.ep_ret.v[k];
             }
             total += (uint32_t)__popcll(m);
         }
@@ -340,7 +365,6 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             const uint64_t wave_base = (uint64_t)blockIdx.x * (kBlock * kVec) + (uint64_t)wave * LPW;
-            float ret_sum = 0.0f;
             for (uint32_t i = lane; i < total; i += 64u) { // one Philox4x32-10 block per finished lane
                 const uint64_t gl = wave_base + list[i];
                 const u32x4 r = draw4(a.seed, a.gid0 + gl, a.tick, kStreamReset);
@@ -352,7 +376,6 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
                 lds.fresh[wave * LPW + i] = fs;
                 if (!ROLL && (STATS || TLIM)) a.ep_start[gl] = tick_next; // the new episode starts at the next tick (plain
                                                                           // store: a non-temporal scattered dword store measured slower)
-                if (STATS && !Env::kConstReward) ret_sum += lds.ret[wave * LPW + i]; // return of the finished episode
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -362,16 +385,14 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
                     const typename ResetLds<Env, VEC>::State fs = lds.fresh[wave * LPW + slot[k]];
 #pragma unroll
                     for (int j = 0; j < NS; ++j) ls[j][k] = fs.v[j];
-                    if (STATS && !Env::kConstReward) d.ep_ret.v[k] = 0.0f;
                     if (ROLL && (STATS || TLIM)) d.ep_start.v[k] = tick_next;
                 }
             }
             if (STATS) { // the wave's private statistics slot: plain read-modify-write, no atomics
                 unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (kBlock / 64) + wave) * 2;
-                if (!Env::kConstReward) {
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) ret_sum += __shfl_xor(ret_sum, off);
-                    ret += (double)ret_sum;
+                if (!Env::kConstReward) { // every lane of the wave finished (shared clock): the open sum is their return
+                    ret += open;
+                    open = 0.0;
                     if (!ROLL && lane == 0) reinterpret_cast<double*>(bs)[1] = ret;
                 }
                 resets += total;
@@ -402,7 +423,6 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
     store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, out.done);
     if (TLIM) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, out.trunc);
     if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, d.beyond);
-    if (STATS && !Env::kConstReward) store_vec<float, kVec, R::NT>(a.ep_ret, base, a.n, FULL, d.ep_ret);
     if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, d.ep_start);
     if (Env::kHasObsExtra) {
         Vec<float, kVec> oc, os;

@@ -104,3 +104,46 @@ def test_rollout_zero_steps_is_a_no_op(gymrs):
         before = eng.get_state()
         eng.rollout(0, action_seed=1)
         assert np.array_equal(before, eng.get_state()) and eng.tick()[0] == 1
+
+
+def test_pendulum_returns_survive_a_change_of_launch_shape(gymrs, twin):
+    """Pendulum's open-episode reward sums live in per-wavefront slots; changing the lanes per work-item
+    (4 -> 16 -> rollout at 4 -> 8) in the middle of episodes must not lose any of them."""
+    n, flags = 20_011, A | S | T
+    p = gymrs.engine.default_params(2)
+    p.max_episode_steps = 30
+    eng = gymrs.BatchedEngine(2, n, flags=flags, params=p)
+    tw = TwinEngine(twin, 2, n, p, flags=flags)
+    eng.reset(seed=4)
+    tw.reset(4)
+    buf = torch.empty(n, dtype=torch.float32, device="cuda:0")
+    t = 0
+
+    def eager(k):
+        nonlocal t
+        for _ in range(k):
+            eng.fill_actions(buf.data_ptr(), seed=9, t=t)
+            eng.step(buf.data_ptr())
+            tw.step(tw.fill_actions(9, t))
+            t += 1
+
+    def fused(k):
+        nonlocal t
+        eng.rollout(k, action_seed=9, action_t0=t)
+        for _ in range(k):
+            tw.step(tw.fill_actions(9, t))
+            t += 1
+
+    eager(7)
+    eng.set_tuning(16)
+    eager(11)
+    fused(9)          # rollout runs 4 lanes per work-item
+    eng.set_tuning(8)
+    eager(13)         # crosses the 30-step limit: every lane's episode closes here
+    fused(25)
+    eager(10)         # and a second time
+    gs, ts = eng.stats(), tw.stats()
+    assert gs[2] == ts[2] == 2 * n and gs[1] == ts[1] == 60 * n
+    assert gs[0] == pytest.approx(ts[0], rel=1e-6)
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    eng.close()

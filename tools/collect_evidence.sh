@@ -13,7 +13,6 @@ REPO=$PWD
 for env in cartpole mountain_car pendulum; do
     python bench.py --env $env > "$OUT/${TAG}_bench_${env}.json" 2> "$OUT/${TAG}_bench_${env}.err"
 done
-python bench.py --env pendulum --stats --cpu-seconds 0 > "$OUT/${TAG}_bench_pendulum_with_return_tracking.json" 2>/dev/null
 for env in cartpole mountain_car pendulum; do
     python bench.py --env $env --rollout 128 --steps 2048 --warmup 256 --cpu-seconds 0 > "$OUT/${TAG}_bench_rollout_${env}.json" 2>/dev/null
 done
