@@ -49,10 +49,30 @@ def cpu_baseline(kind: int, target_seconds: float):
     rate = 2_000_000 / max(secs, 1e-9)
     n = int(min(max(rate * target_seconds, 2_000_000), 4e9))
     secs, out = orc.baseline_loop(kind, n, 0, 0)
+    # also an "all host cores" figure = one independent single-env loop per core (threads; the C
+    # loop runs without the GIL).  Reported beside the single-thread value, never instead of it.
+    import threading
+
+    cores = os.cpu_count() or 1
+    per_thread = max(int(rate * min(target_seconds, 3.0)), 1_000_000)
+    times = [0.0] * cores
+
+    def work(i):
+        times[i] = orc.baseline_loop(kind, per_thread, 0, i)[0]
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    all_wall = time.perf_counter() - t0
     return {
         "value": n / secs,
         "unit": "env-steps/s",
         "cores": 1,
+        "all_cores": {"value": cores * per_thread / all_wall, "cores": cores,
+                      "sample": f"{cores} threads x {per_thread} steps, {all_wall:.1f} s wall"},
         "kind": "port",
         "sample": f"{n} consecutive Env::step() calls of ONE env (f64 C restatement of gym-rs step()+reset, "
                   f"random actions, reset on done; loop shape of examples/cartpole.rs:15-30, RenderMode::None), "

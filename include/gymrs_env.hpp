@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdint>
 #include <limits>
+#include <array>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -82,7 +83,11 @@ public:
         state_dim_ = d;
     }
     ~VecEnv() { gymrs_engine_destroy(e_); }
-    VecEnv(const VecEnv&) = delete;
+    // `Env: Clone` (core.rs:25): a deep copy on the device, including the RNG position (seed, tick)
+    VecEnv(const VecEnv& other) : kind_(other.kind_), n_(other.n_), state_dim_(other.state_dim_)
+    {
+        check(gymrs_engine_clone(other.e_, &e_));
+    }
     VecEnv& operator=(const VecEnv&) = delete;
 
     std::uint64_t reset(std::optional<std::uint64_t> seed, const float* bounds_low_high = nullptr)
@@ -98,6 +103,27 @@ public:
         check(gymrs_sync(e_));
     }
     void sync() { check(gymrs_sync(e_)); }
+    // the loop of examples/cartpole.rs:15-30 (random action, step, reset on done) for every lane, fused into one launch
+    void rollout(std::uint32_t n_steps, std::uint64_t action_seed, std::uint64_t action_t0 = 0)
+    {
+        check(gymrs_rollout(e_, n_steps, action_seed, action_t0));
+    }
+    std::array<double, 4> stats() // {sum_return, sum_length, n_episodes, n_steps}
+    {
+        std::array<double, 4> out{};
+        check(gymrs_stats(e_, out.data()));
+        return out;
+    }
+    // `Env: Serialize` (core.rs:25): everything a step can observe, as an opaque blob
+    std::vector<unsigned char> snapshot()
+    {
+        std::uint64_t bytes = 0;
+        check(gymrs_snapshot_size(e_, &bytes));
+        std::vector<unsigned char> blob(bytes);
+        check(gymrs_snapshot_save(e_, blob.data(), bytes));
+        return blob;
+    }
+    void restore(const std::vector<unsigned char>& blob) { check(gymrs_snapshot_load(e_, blob.data(), blob.size())); }
     std::vector<float> state(std::uint64_t first, std::uint64_t count)
     {
         std::vector<float> out(count * state_dim_);

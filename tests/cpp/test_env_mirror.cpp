@@ -93,6 +93,23 @@ int main()
         check(gymrs_stats(env.handle(), st));
         REQUIRE(st[3] == 4096.0 * 50 && st[2] > 0 && st[0] == st[1]);
     }
+    {
+        // the examples' loop fused into one launch; Clone and snapshot/restore continue identically
+        VecEnv a(GYMRS_MOUNTAIN_CAR, 10000, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT);
+        a.reset(3);
+        a.rollout(150, 11, 0);
+        VecEnv b(a); // Env: Clone
+        const std::vector<unsigned char> blob = a.snapshot();
+        VecEnv c(GYMRS_MOUNTAIN_CAR, 10000, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT);
+        c.restore(blob);
+        a.rollout(150, 11, 150);
+        b.rollout(150, 11, 150);
+        c.rollout(150, 11, 150);
+        const auto sa = a.stats(), sb = b.stats(), sc = c.stats();
+        REQUIRE(sa[3] == 10000.0 * 300 && sa[2] >= 10000.0 && sa[0] == -sa[1]); // 200-step limit: every lane finished once
+        REQUIRE(sa == sb && sa == sc);
+        REQUIRE(a.state(0, 10000) == b.state(0, 10000) && a.state(0, 10000) == c.state(0, 10000));
+    }
     std::printf("CPP_MIRROR_OK\n");
     return 0;
 }
