@@ -35,7 +35,7 @@
 namespace gymrs {
 
 template <class Env, int VEC, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
+__device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
 {
     constexpr int kVec = VEC;
     constexpr int LPB = kBlock * kVec;
@@ -45,6 +45,9 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
     GYMRS_STAMP(0);
     TileRegs<Env, VEC, FLAGS> d;
     load_tile<Env, VEC, FLAGS, FULL>(a, base, d);
+    // A replayed HIP graph keeps the tick on the device.  Resolved here, BEHIND the state loads: ahead of them
+    // the branch makes every wave wait for the whole kernel-argument fetch before it issues its first load.
+    if (a.tick_base) a.tick += *a.tick_base;
     // Episode statistics: every wavefront owns one {finished episodes, sum of returns} slot.  The old value
     // is fetched right behind the state loads (after them, so that the slot pointer does not split the
     // kernel-argument fetch in two) and the updated value leaves with the wave's last stores: the hot
@@ -90,7 +93,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 16 / 
     a.s[3] = s3;
     a.action = action;
     a.n = n;
-    if (rest.tick_base) a.tick = rest.tick + *rest.tick_base; // replayed HIP graph: the tick lives on the device
     // workgroup-uniform: every workgroup but the last runs the unguarded body
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
         step_block<Env, VEC, FLAGS, true>(a, c, lds);
