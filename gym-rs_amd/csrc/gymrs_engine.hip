@@ -861,7 +861,7 @@ struct SnapshotHeader {
     char magic[8]; // "GYMRSNAP"
     uint32_t version, kind;
     uint64_t n, gid0;
-    uint32_t flags, state_dim, epoch, n_stat_blocks, max_steps, has_ret; // has_ret: now the open_vec of the engine
+    uint32_t flags, state_dim, epoch, n_stat_blocks, max_steps, open_vec;
     uint64_t seed, tick, uniform_start;
     double n_steps_total;
     float lo[4], hi[4], max_torque;
@@ -975,7 +975,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
     h.epoch = e->epoch;
     h.n_stat_blocks = e->n_stat_blocks;
     h.max_steps = e->max_steps;
-    h.has_ret = (uint32_t)e->open_vec; // lanes per work-item the open-episode sums were last updated with
+    h.open_vec = (uint32_t)e->open_vec; // lanes per work-item the open-episode sums were last updated with
     h.seed = e->seed;
     h.tick = e->tick;
     h.uniform_start = e->uniform_start;
@@ -1028,7 +1028,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     std::memcpy(e->lo, h.lo, sizeof(e->lo));
     std::memcpy(e->hi, h.hi, sizeof(e->hi));
     e->max_torque = h.max_torque;
-    e->open_vec = (int)h.has_ret;
+    e->open_vec = (int)h.open_vec;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
     return GYMRS_OK;
 }
