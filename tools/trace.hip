@@ -27,7 +27,7 @@ int main(int argc, char** argv)
     unsigned long long t0 = ~0ull;
     for (size_t w = 0; w < waves; ++w) t0 = std::min(t0, h[w * 8]);
     const char* names[7] = {"start", "loads issued", "loads landed", "physics done", "reset done", "stores issued", "end (stores acked)"};
-    printf("per-wave s_memtime stamps relative to the earliest wave start (ticks; 100 MHz constant clock => 10 ns/tick)\n");
+    printf("per-wave s_memtime stamps relative to the earliest wave start (s_memtime ticks = shader-clock cycles, ~2.4 GHz; start stamps of different XCDs are not comparable, phase durations are)\n");
     for (int s = 0; s < 7; ++s) {
         std::vector<long long> v(waves);
         for (size_t w = 0; w < waves; ++w) v[w] = (long long)(h[w * 8 + s] - t0);
