@@ -451,7 +451,9 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
         e->beyond = reinterpret_cast<uint8_t*>(b + at_beyond);
         e->ep_start = reinterpret_cast<uint32_t*>(b + at_start);
     }
-    e->n_stat_blocks = step_grid(n_envs, 4) * (kBlock / 64); // one statistics slot per wavefront (most waves at vec = 4)
+    // one statistics slot per wavefront: most waves at 4 lanes per work-item (256 lanes per wave), rounded up to whole
+    // workgroups of up to 16 waves
+    e->n_stat_blocks = (uint32_t)((((n_envs + 255) / 256) + 15) / 16 * 16);
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));

@@ -7,7 +7,7 @@
 
 namespace gymrs {
 
-constexpr int kBlock = 256; // 4 wavefronts of 64
+constexpr int kBlock = 256; // work-items per workgroup of the small kernels (reset, fill, statistics) and of the rollout kernel
 constexpr uint32_t kFlagNonTemporal = 0x100u; // internal launch flag (not an engine flag): non-temporal loads/stores
 
 // Everything one step() launch needs.  Device pointers are SoA arrays of n lanes.
@@ -57,10 +57,10 @@ struct ResetArgs {
     SampleBox box;
 };
 
-// Number of workgroups step_kernel uses for n lanes at `vec` lanes per work-item (4, 8 or 16).
-inline uint32_t step_grid(uint64_t n, int vec)
+// Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4, 8 or 16).
+inline uint32_t step_grid(uint64_t n, int vec, int threads = kBlock)
 {
-    const uint64_t per_block = (uint64_t)kBlock * vec;
+    const uint64_t per_block = (uint64_t)threads * vec;
     return (uint32_t)((n + per_block - 1) / per_block);
 }
 

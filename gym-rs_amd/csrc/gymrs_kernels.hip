@@ -38,7 +38,7 @@ template <class Env, int VEC, uint32_t FLAGS, bool FULL>
 __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
 {
     constexpr int kVec = VEC;
-    constexpr int LPB = kBlock * kVec;
+    constexpr int LPB = Env::kThreads * kVec;
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
     const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * kVec;
@@ -55,7 +55,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     // has exactly one writer per launch.)
     unsigned long long old_resets = 0;
     double old_ret = 0.0, open = 0.0;
-    const size_t wave_slot = (size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const size_t wave_slot = (size_t)blockIdx.x * (Env::kThreads / 64) + (threadIdx.x >> 6);
     if (STATS) {
         const unsigned long long* bs = a.block_stats + wave_slot * 2;
         old_resets = bs[0];
@@ -80,11 +80,11 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // placed first, so that kernel-argument preloading (-mllvm -amdgpu-kernarg-preload-count, see build.py) can
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 template <class Env, int VEC, uint32_t FLAGS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
+__global__ __launch_bounds__(Env::kThreads) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
     float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n, const StepArgs rest,
     const typename Env::Consts c)
 {
-    constexpr int LPB = kBlock * VEC;
+    constexpr int LPB = Env::kThreads * VEC;
     __shared__ ResetLds<Env, VEC> lds;
     StepArgs a = rest;
     a.s[0] = s0;
@@ -203,7 +203,7 @@ __global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned lo
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0, stream, a.s[0], a.s[1],
                        a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }

@@ -12,7 +12,7 @@ namespace gymrs {
 // advance_tile, step after step, and leaves the arrays as the last of those steps would.
 template <class Env, int VEC, uint32_t FLAGS, bool FULL>
 __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, const typename Env::Consts& c,
-                                              ResetLds<Env, VEC>& lds)
+                                              ResetLds<Env, VEC, kBlock>& lds)
 {
     constexpr int kVec = VEC;
     using R = TileRegs<Env, VEC, FLAGS>;
@@ -70,7 +70,7 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
             a.truncate_all = (a.tick + 1 - ustart >= c.max_steps) ? 1u : 0u;
             if (a.truncate_all && R::AUTO) ustart = a.tick + 1;
         }
-        advance_tile<Env, VEC, FLAGS, FULL, true>(a, c, base, d, lds, resets, ret, open, out);
+        advance_tile<Env, VEC, FLAGS, FULL, true, kBlock>(a, c, base, d, lds, resets, ret, open, out);
     }
     store_tile<Env, VEC, FLAGS, FULL, true>(a, base, d, out);
     if (R::STATS && (threadIdx.x & 63u) == 0) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(16 / VEC
     const StepArgs a, const RolloutArgs r, const typename Env::Consts c)
 {
     constexpr int LPB = kBlock * VEC;
-    __shared__ ResetLds<Env, VEC> lds;
+    __shared__ ResetLds<Env, VEC, kBlock> lds;
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
         rollout_block<Env, VEC, FLAGS, true>(a, r, c, lds);
     else

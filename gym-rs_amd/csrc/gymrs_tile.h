@@ -14,7 +14,7 @@ namespace gymrs {
 #define GYMRS_STAMP(slot_)                                                                                   \
     do {                                                                                                     \
         if (a.trace && (threadIdx.x & 63u) == 0)                                                             \
-            a.trace[((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
+            a.trace[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define GYMRS_STAMP(slot_) do { } while (0)
@@ -95,6 +95,7 @@ struct CartPoleT {
     static constexpr bool kHasBeyond = true;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
+    static constexpr int kThreads = 512; // work-items per workgroup of the per-step kernel: 8 waves measured 2 % faster than 4 here
     __device__ static bool valid(Action a) { return a < 2; } // Discrete(2).contains, discrete.rs:14-19
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -122,6 +123,7 @@ struct MountainCarT {
     static constexpr bool kHasBeyond = false;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
+    static constexpr int kThreads = 256; // (512 measured 1-2 % slower for this short kernel)
     __device__ static bool valid(Action a) { return a < 3; } // Discrete(3)
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -150,6 +152,7 @@ struct PendulumT { // spec-derived, not in the reference
     // No termination and no invalid actions: every lane's episode clock is the same, so the time limit is a
     // kernel argument (StepArgs::truncate_all) instead of a per-lane compare against a dense ep_start read.
     static constexpr bool kNeverTerminates = true;
+    static constexpr int kThreads = 256;
     __device__ static bool valid(Action) { return true; } // a Box action is clipped, never rejected
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -200,9 +203,9 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
 
 // LDS of one workgroup for the auto-reset hand-off: every wavefront uses its own 256-entry segment
 // (list of finished lanes, their fresh states); waves never touch each other's.
-template <class Env, int VEC>
+template <class Env, int VEC, int THREADS = Env::kThreads>
 struct ResetLds {
-    static constexpr int kLanes = kBlock * VEC;
+    static constexpr int kLanes = THREADS * VEC;
     uint16_t list[kLanes];
     struct alignas(Env::kState * 4) State {
         float v[Env::kState];
@@ -243,9 +246,9 @@ struct StepOut {
 // such an env never terminates, so all lanes share one episode clock, finish together, and the return of the
 // finished episodes of a wave is just that sum -- no per-lane return accumulator in HBM (which cost 8 B per
 // lane-step: 29.6 vs 23.4 us per 2^22-lane step).  The caller loads/stores `open` (StepArgs::wave_open).
-template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false>
+template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads>
 __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
-                                             TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC>& lds, unsigned long long& resets,
+                                             TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC, THREADS>& lds, unsigned long long& resets,
                                              double& ret, double& open, StepOut<VEC>& out)
 {
     static_assert(Env::kConstReward || Env::kNeverTerminates,
@@ -364,13 +367,13 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             // must not move LDS accesses across the hand-over points.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint64_t wave_base = (uint64_t)blockIdx.x * (kBlock * kVec) + (uint64_t)wave * LPW;
+            const uint64_t wave_base = base - (uint64_t)lane * kVec; // global lane of this wave's first lane
             for (uint32_t i = lane; i < total; i += 64u) { // one Philox4x32-10 block per finished lane
                 const uint64_t gl = wave_base + list[i];
                 const u32x4 r = draw4(a.seed, a.gid0 + gl, a.tick, kStreamReset);
                 float ns[NS];
                 Env::sample(r, a.box, ns);
-                typename ResetLds<Env, VEC>::State fs;
+                typename ResetLds<Env, VEC, THREADS>::State fs;
 #pragma unroll
                 for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
                 lds.fresh[wave * LPW + i] = fs;
@@ -382,14 +385,14 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
 #pragma unroll
             for (int k = 0; k < kVec; ++k) {
                 if (need_reset[k]) {
-                    const typename ResetLds<Env, VEC>::State fs = lds.fresh[wave * LPW + slot[k]];
+                    const typename ResetLds<Env, VEC, THREADS>::State fs = lds.fresh[wave * LPW + slot[k]];
 #pragma unroll
                     for (int j = 0; j < NS; ++j) ls[j][k] = fs.v[j];
                     if (ROLL && (STATS || TLIM)) d.ep_start.v[k] = tick_next;
                 }
             }
             if (STATS) { // the wave's private statistics slot: plain read-modify-write, no atomics
-                unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (kBlock / 64) + wave) * 2;
+                unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (THREADS / 64) + wave) * 2;
                 if (!Env::kConstReward) { // every lane of the wave finished (shared clock): the open sum is their return
                     ret += open;
                     open = 0.0;
