@@ -76,6 +76,7 @@ struct gymrs_engine {
     uint32_t* ep_start = nullptr;
     double* wave_open = nullptr; // per-wavefront sum of the rewards of the open episodes (Pendulum + TRACK_STATS)
     int open_vec = 0;            // lanes per work-item of the launch that last updated wave_open (0 = none yet)
+    int trunc_held = -1;         // Pendulum: the uniform value the `truncated` array holds (-1 = unknown: write it)
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
     void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
@@ -158,6 +159,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.tick = e->tick;
     a.box = make_sample_box(e->lo, e->hi, e->state_dim);
     a.truncate_all = (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT) && e->tick + 1 - e->uniform_start >= e->max_steps) ? 1u : 0u;
+    a.skip_trunc_store = (e->kind == GYMRS_PENDULUM && e->trunc_held == (int)a.truncate_all) ? 1u : 0u;
     a.trace = e->trace;
     return a;
 }
@@ -579,6 +581,7 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
     HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
     e->open_vec = 0;
+    e->trunc_held = 0; // reset_kernel cleared the flags
     HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
     e->n_steps_total = 0;
     return GYMRS_OK;
@@ -603,6 +606,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     StepArgs a = step_args(e, actions_dev);
     HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
     e->tick += 1;
+    if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
     if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick; // all lanes were re-armed
     e->n_steps_total += (double)e->n;
     return GYMRS_OK;
@@ -616,6 +620,7 @@ gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_se
     if (n_steps == 0) return GYMRS_OK;
     HIP_TRY(hipSetDevice(e->device));
     StepArgs a = step_args(e, nullptr);
+    a.skip_trunc_store = 0; // the kernel stores the LAST step's flags, whatever the array holds now
     RolloutArgs r;
     r.action_seed = action_seed;
     r.action_t0 = action_t0;
@@ -628,9 +633,11 @@ gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_se
     HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
     for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
         e->tick += 1;
-        if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT) && (e->flags & GYMRS_AUTO_RESET) &&
-            e->tick - e->uniform_start >= e->max_steps)
-            e->uniform_start = e->tick;
+        if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) {
+            const bool hit = e->tick - e->uniform_start >= e->max_steps;
+            e->trunc_held = hit ? 1 : 0; // the rollout kernel stores the last step's flags
+            if (hit && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
+        }
     }
     e->n_steps_total += (double)e->n * (double)n_steps;
     return GYMRS_OK;
@@ -720,6 +727,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
         e->tick += 1;
+        if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
         if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
     }
     e->n_steps_total += (double)e->n * (double)n_steps;
@@ -925,6 +933,7 @@ void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
     dst->vec = src->vec;
     dst->nt_mode = src->nt_mode;
     dst->open_vec = src->open_vec;
+    dst->trunc_held = src->trunc_held;
 }
 } // namespace
 } // extern "C++"
@@ -1031,6 +1040,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     std::memcpy(e->hi, h.hi, sizeof(e->hi));
     e->max_torque = h.max_torque;
     e->open_vec = (int)h.open_vec;
+    e->trunc_held = -1; // whatever the arrays held before the load: rewrite the flags on the next step
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
     return GYMRS_OK;
 }

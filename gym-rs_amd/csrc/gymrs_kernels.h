@@ -31,6 +31,7 @@ struct StepArgs {
     const unsigned long long* tick_base; // device-resident tick for captured HIP graphs (NULL in eager launches)
     SampleBox box;      // reset sampling box, prepared on the host (gymrs_philox.h)
     uint32_t truncate_all; // envs that never terminate (Pendulum): this step hits the time limit for every lane
+    uint32_t skip_trunc_store; // same envs: the `truncated` array already holds this step's (uniform) value
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
 };
 

@@ -423,8 +423,10 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
 #pragma unroll
     for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, d.st[j]);
     store_vec<float, kVec, R::NT>(a.reward, base, a.n, FULL, out.reward);
-    store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, out.done);
-    if (TLIM) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, out.trunc);
+    // An env that never terminates never changes `done` (reset() zeroed it), and its `truncated` flag is the same
+    // for every lane: neither is rewritten while it already holds the right value (2 of Pendulum's 34 real bytes).
+    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, out.done);
+    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, out.trunc);
     if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, d.beyond);
     if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, d.ep_start);
     if (Env::kHasObsExtra) {

@@ -538,3 +538,48 @@ def test_step_many_ring_pendulum_f32_actions(gymrs, twin):
     gs, ts = eng.stats(), tw.stats()
     assert gs[1] == ts[1] == n * 40 and gs[2] == ts[2] == n * 2 and gs[0] == pytest.approx(ts[0], rel=1e-5)
     eng.close()
+
+
+@pytest.mark.parametrize("auto", [True, False])
+def test_pendulum_flags_follow_the_twin_on_every_step(gymrs, twin, auto):
+    """Pendulum never terminates and truncates all lanes at once, so the kernel rewrites `done` / `truncated` only
+    when their (uniform) value changes; the arrays must still read right after EVERY step, across the time limit,
+    after a rollout, and after a snapshot is loaded into another engine."""
+    n = 3001
+    flags = gymrs.TIME_LIMIT | ((gymrs.AUTO_RESET | gymrs.TRACK_STATS) if auto else 0)
+    p = gymrs.engine.default_params(2)
+    p.max_episode_steps = 5
+    eng = gymrs.BatchedEngine(2, n, flags=flags, params=p)
+    tw = TwinEngine(twin, 2, n, p, flags=flags)
+    eng.reset(seed=6)
+    tw.reset(6)
+    buf = torch.empty(n, dtype=torch.float32, device="cuda:0")
+
+    def check(tag):
+        gr, gd, gt = eng.get_step_result()
+        tr, td, tt = tw.get_result()
+        assert np.array_equal(gd, td) and np.array_equal(gt, tt), tag
+        assert np.array_equal(gr.view(np.uint32), tr.view(np.uint32)), tag
+
+    t = 0
+    for t in range(13):
+        eng.fill_actions(buf.data_ptr(), seed=3, t=t)
+        eng.step(buf.data_ptr())
+        tw.step(tw.fill_actions(3, t))
+        check(("step", t))
+    eng.rollout(4, action_seed=3, action_t0=13)   # ends exactly on / off a limit step depending on `auto`
+    for t in range(13, 17):
+        tw.step(tw.fill_actions(3, t))
+    check("rollout")
+    other = gymrs.BatchedEngine(2, n, flags=flags, params=p)
+    other.reset(seed=99)
+    other.restore(eng.snapshot())
+    for e in (eng, other):
+        e.fill_actions(buf.data_ptr(), seed=3, t=17)
+        e.step(buf.data_ptr())
+    tw.step(tw.fill_actions(3, 17))
+    check("after snapshot, original")
+    gr, gd, gt = other.get_step_result()
+    assert np.array_equal(gt, tw.get_result()[2]) and np.array_equal(gd, tw.get_result()[1])
+    eng.close()
+    other.close()
