@@ -74,6 +74,8 @@ struct gymrs_engine {
     uint8_t* truncated = nullptr;
     uint8_t* beyond = nullptr;
     uint32_t* ep_start = nullptr;
+    uint32_t* wave_clean = nullptr; // per-wavefront: its part of `reward` holds the env's constant reward (see step_block)
+    int clean_shape = 0;           // lanes per workgroup row the flags were written with (vec * threads); 0 = all clear
     double* wave_open = nullptr; // per-wavefront sum of the rewards of the open episodes (Pendulum + TRACK_STATS)
     int open_vec = 0;            // lanes per work-item of the launch that last updated wave_open (0 = none yet)
     int trunc_held = -1;         // Pendulum: the uniform value the `truncated` array holds (-1 = unknown: write it)
@@ -151,6 +153,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.beyond = e->beyond;
     a.ep_start = e->ep_start;
     a.wave_open = e->wave_open;
+    a.wave_clean = e->wave_clean;
     a.block_stats = e->block_stats;
     a.err = e->err;
     a.n = e->n;
@@ -319,6 +322,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
     (void)hipFree(e->wave_open);
+    (void)hipFree(e->wave_clean);
     (void)hipFree(e->err);
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     (void)hipFree(e->tick_dev);
@@ -458,6 +462,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     e->n_stat_blocks = (uint32_t)((((n_envs + 255) / 256) + 15) / 16 * 16);
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
     chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
+    chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
     chk(dev_alloc(&e->stats_acc, 3));
@@ -582,6 +587,8 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
     e->open_vec = 0;
     e->trunc_held = 0; // reset_kernel cleared the flags
+    HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
+    e->clean_shape = 0;
     HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
     e->n_steps_total = 0;
     return GYMRS_OK;
@@ -590,8 +597,20 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
 // Pendulum's open-episode reward sums live in per-wavefront slots whose lane coverage depends on the lanes per
 // work-item of the launch: when that changes, gather them into slot 0 (every launch shape has a wave 0) so that
 // no slot the new shape never visits keeps a stranded partial sum.
+// The same for the reward-elision flags (step_block): they describe a wave's lanes, so a launch of another shape
+// starts from "rewrite everything".
+static gymrs_status prepare_wave_flags(gymrs_engine* e, int vec)
+{
+    if (e->clean_shape != vec) {
+        if (e->clean_shape != 0) HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream));
+        e->clean_shape = vec;
+    }
+    return GYMRS_OK;
+}
+
 static gymrs_status prepare_open_sums(gymrs_engine* e, int vec)
 {
+    if (gymrs_status st = prepare_wave_flags(e, vec)) return st;
     if (e->kind != GYMRS_PENDULUM || (e->flags & (GYMRS_TRACK_STATS | GYMRS_AUTO_RESET)) != (GYMRS_TRACK_STATS | GYMRS_AUTO_RESET)) return GYMRS_OK;
     if (e->open_vec != 0 && e->open_vec != vec) HIP_TRY(launch_fold_open(e->wave_open, e->n_stat_blocks, e->stream));
     e->open_vec = vec;
@@ -1041,6 +1060,8 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     e->max_torque = h.max_torque;
     e->open_vec = (int)h.open_vec;
     e->trunc_held = -1; // whatever the arrays held before the load: rewrite the flags on the next step
+    HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
+    e->clean_shape = 0;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
     return GYMRS_OK;
 }

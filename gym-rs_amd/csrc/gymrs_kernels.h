@@ -21,6 +21,7 @@ struct StepArgs {
     uint8_t* truncated; // written only with GYMRS_TIME_LIMIT
     uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
     uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
+    uint32_t* wave_clean; // [n_waves] constant-reward envs under auto-reset: != 0 = the wave's part of `reward` holds the constant
     double* wave_open;  // [n_waves] Pendulum with GYMRS_TRACK_STATS: per-wavefront sum of the rewards of the open episodes
     unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1

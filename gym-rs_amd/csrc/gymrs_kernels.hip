@@ -64,10 +64,18 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
             open = a.wave_open[wave_slot];
         }
     }
+    // MountainCar pays -1.0 on every step (mountain_car.rs:423; SURVEY 8a row a6 "may be elided ... but counted in
+    // algorithmic bytes"): once a wave's part of `reward` holds the constant it is not rewritten until a step pays
+    // something else there (an invalid action).  A per-wave flag remembers it.  (CartPole under auto-reset is
+    // constant too, but its kernel is VALU-bound: there the flag load costs more than the stores save.)
+    constexpr bool ELIDE = AUTO && Env::kConstReward && Env::kElideConstReward;
+    uint32_t clean = 0;
+    if (ELIDE) clean = a.wave_clean[wave_slot];
     GYMRS_STAMP(1);
     StepOut<VEC> out;
     advance_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret, open, out);
-    store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out);
+    store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
+    if (ELIDE && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
     if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
     GYMRS_STAMP(6);
 }

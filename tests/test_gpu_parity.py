@@ -583,3 +583,38 @@ def test_pendulum_flags_follow_the_twin_on_every_step(gymrs, twin, auto):
     assert np.array_equal(gt, tw.get_result()[2]) and np.array_equal(gd, tw.get_result()[1])
     eng.close()
     other.close()
+
+
+def test_mountain_car_reward_array_stays_right_around_invalid_actions(gymrs, twin):
+    """MountainCar's constant reward is not rewritten while the array already holds it; a step with an invalid
+    action pays 0 on that lane (lane untouched), and the step after must put -1 back."""
+    n = 5000
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    eng = gymrs.BatchedEngine(1, n, flags=flags)
+    eng.reset(seed=3)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    for t in range(3):
+        eng.fill_actions(buf.data_ptr(), seed=1, t=t)
+        eng.step(buf.data_ptr())
+        assert (eng.get_step_result()[0] == -1.0).all()
+    bad = torch.ones(n, dtype=torch.uint8, device="cuda:0")
+    bad[1234] = 7
+    eng.step(bad.data_ptr())
+    with pytest.raises(gymrs.InvalidActionError):
+        eng.sync()
+    r = eng.get_step_result()[0]
+    assert r[1234] == 0.0 and (np.delete(r, 1234) == -1.0).all()
+    eng.fill_actions(buf.data_ptr(), seed=1, t=4)
+    eng.step(buf.data_ptr())
+    eng.sync()
+    assert (eng.get_step_result()[0] == -1.0).all()
+    # a change of launch shape and a snapshot load both start from "rewrite everything"
+    eng.set_tuning(8)
+    eng.step(buf.data_ptr())
+    other = gymrs.BatchedEngine(1, n, flags=flags)
+    other.reset(seed=8)
+    other.restore(eng.snapshot())
+    other.step(buf.data_ptr())
+    assert (eng.get_step_result()[0] == -1.0).all() and (other.get_step_result()[0] == -1.0).all()
+    eng.close()
+    other.close()
