@@ -34,11 +34,11 @@
 
 namespace gymrs {
 
-template <class Env, int VEC, uint32_t FLAGS, bool FULL>
-__device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC>& lds)
+template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
+__device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds)
 {
     constexpr int kVec = VEC;
-    constexpr int LPB = Env::kThreads * kVec;
+    constexpr int LPB = THREADS * kVec;
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
     const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * kVec;
@@ -55,7 +55,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     // has exactly one writer per launch.)
     unsigned long long old_resets = 0;
     double old_ret = 0.0, open = 0.0;
-    const size_t wave_slot = (size_t)blockIdx.x * (Env::kThreads / 64) + (threadIdx.x >> 6);
+    const size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); // = the global wave index
     if (STATS) {
         const unsigned long long* bs = a.block_stats + wave_slot * 2;
         old_resets = bs[0];
@@ -73,7 +73,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     if (ELIDE) clean = a.wave_clean[wave_slot];
     GYMRS_STAMP(1);
     StepOut<VEC> out;
-    advance_tile<Env, VEC, FLAGS, FULL>(a, c, base, d, lds, old_resets, old_ret, open, out);
+    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out);
     store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
     if (ELIDE && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
     if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
@@ -87,13 +87,15 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // The pointers and the lane count the first instructions of a wave need are separate scalar kernel parameters
 // placed first, so that kernel-argument preloading (-mllvm -amdgpu-kernarg-preload-count, see build.py) can
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
-template <class Env, int VEC, uint32_t FLAGS>
-__global__ __launch_bounds__(Env::kThreads) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
+// THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
+// workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
+template <class Env, int VEC, uint32_t FLAGS, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
     float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n, const StepArgs rest,
     const typename Env::Consts c)
 {
-    constexpr int LPB = Env::kThreads * VEC;
-    __shared__ ResetLds<Env, VEC> lds;
+    constexpr int LPB = THREADS * VEC;
+    __shared__ ResetLds<Env, VEC, THREADS> lds;
     StepArgs a = rest;
     a.s[0] = s0;
     a.s[1] = s1;
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(Env::kThreads) __attribute__((amdgpu_waves_per_eu(1
     a.n = n;
     // workgroup-uniform: every workgroup but the last runs the unguarded body
     if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
-        step_block<Env, VEC, FLAGS, true>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
-        step_block<Env, VEC, FLAGS, false>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -211,7 +213,14 @@ __global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned lo
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0, stream, a.s[0], a.s[1],
+    if constexpr (Env::kThreads != kBlock) {
+        if (a.n >= (uint64_t)Env::kThreads * VEC * 512) { // >= 2 big workgroups per CU
+            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
+                               stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
                        a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }

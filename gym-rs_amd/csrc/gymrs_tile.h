@@ -97,7 +97,7 @@ struct CartPoleT {
     static constexpr bool kHasBeyond = true;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
-    static constexpr int kThreads = 512; // work-items per workgroup of the per-step kernel: 8 waves measured 2 % faster than 4 here
+    static constexpr int kThreads = 512; // work-items per workgroup of the per-step kernel at >= 2^20 lanes: 8 waves measured 2 % faster than 4
     __device__ static bool valid(Action a) { return a < 2; } // Discrete(2).contains, discrete.rs:14-19
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
