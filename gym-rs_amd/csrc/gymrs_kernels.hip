@@ -103,8 +103,9 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 /
     a.s[3] = s3;
     a.action = action;
     a.n = n;
-    // workgroup-uniform: every workgroup but the last runs the unguarded body
-    if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
+    // wave-uniform: every wavefront whose 64 * VEC lanes all exist runs the unguarded body; only the one that
+    // straddles n (and the empty ones behind it) takes the guarded per-lane code
+    if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= a.n)
         step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(16 / VEC
 {
     constexpr int LPB = kBlock * VEC;
     __shared__ ResetLds<Env, VEC, kBlock> lds;
-    if ((uint64_t)(blockIdx.x + 1) * LPB <= a.n)
+    if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= a.n) // wave-uniform, see step_kernel
         rollout_block<Env, VEC, FLAGS, true>(a, r, c, lds);
     else
         rollout_block<Env, VEC, FLAGS, false>(a, r, c, lds);
