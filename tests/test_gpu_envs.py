@@ -168,3 +168,21 @@ def test_snapshot_rejects_a_mismatched_engine(gymrs):
             a.restore(blob[:64])
         with pytest.raises(gymrs.GymrsError):
             a.restore(b"NOTASNAP" + blob[8:])
+
+
+def test_closed_loop_example_runs_and_balances(tmp_path):
+    """examples/closed_loop_policy.py: zero-copy observation columns in torch, a linear policy on the engine's
+    stream.  The controller keeps the pole up far longer than the ~22 steps of a random policy."""
+    import re
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    out = subprocess.run([sys.executable, str(root / "examples" / "closed_loop_policy.py"), "--n-envs", "8192", "--steps", "600"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    m = re.search(r"finished episodes: (\d+), mean return ([0-9.]+)", out.stdout)
+    assert m, out.stdout
+    episodes, mean_return = int(m.group(1)), float(m.group(2))
+    assert episodes == 0 or mean_return > 100.0, out.stdout
