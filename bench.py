@@ -97,6 +97,8 @@ def main() -> int:
     ap.add_argument("--rollout", type=int, default=0, metavar="R",
                     help="NOT the headline: fused gymrs_rollout launches of R steps each (state stays in registers, "
                          "observations of intermediate steps are not materialised); reported with mode=fused_rollout")
+    ap.add_argument("--record", action="store_true",
+                    help="with --rollout: gymrs_rollout_record, i.e. every step's observation/action/reward/done is kept")
     ap.add_argument("--graph", action="store_true", help="replay captured HIP graphs (pays for small batches only)")
     ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
     args = ap.parse_args()
@@ -144,12 +146,26 @@ def main() -> int:
     stride = actions.stride(0) * actions.element_size()
     eng.reset(seed=0)
 
+    rec = None
+    if args.rollout and args.record:
+        rs = (n + 15) // 16 * 16
+        dev = f"cuda:{local_rank}"
+        rec = {"obs": torch.empty((args.rollout, eng.obs_dim, rs), dtype=torch.float32, device=dev),
+               "actions": torch.empty((args.rollout, rs), dtype=act_dtype, device=dev),
+               "reward": torch.empty((args.rollout, rs), dtype=torch.float32, device=dev),
+               "done": torch.empty((args.rollout, rs), dtype=torch.uint8, device=dev)}
+        torch.cuda.synchronize()
+
     def run(k):
         if args.rollout:
             done = 0
             while done < k:
                 r = min(args.rollout, k - done)
-                eng.rollout(r, action_seed=1, action_t0=done)
+                if rec is not None:
+                    eng.rollout_record(r, 1, done, obs=rec["obs"].data_ptr(), actions=rec["actions"].data_ptr(),
+                                       reward=rec["reward"].data_ptr(), done=rec["done"].data_ptr(), lane_stride=rec["obs"].shape[2])
+                else:
+                    eng.rollout(r, action_seed=1, action_t0=done)
                 done += r
         else:
             eng.step_many(actions.data_ptr(), stride, nbuf, k, use_graph=args.graph)
@@ -255,7 +271,7 @@ def main() -> int:
         if args.rollout:
             # the fused kernel touches HBM once per launch of R steps: it is VALU-bound, the HBM roofline of the
             # per-step kernel does not apply and is not claimed
-            out["mode"] = "fused_rollout"
+            out["mode"] = "fused_rollout_recorded" if args.record else "fused_rollout"
             out["config"]["steps_per_launch"] = args.rollout
             out["config"]["workload"] = workload + f" -- fused rollout, {args.rollout} steps per launch (NOT the per-step headline)"
             out["roofline"] = {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,

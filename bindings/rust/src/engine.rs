@@ -113,6 +113,15 @@ impl Engine {
         check(unsafe { ffi::gymrs_rollout(self.raw, n_steps, action_seed, action_t0) });
     }
 
+    /// `rollout` that also keeps every step's observation / action / reward / done in device buffers.
+    ///
+    /// # Safety
+    /// The pointers in `out` must be device buffers of the sizes `include/gymrs_amd.h` documents for `gymrs_trajectory`
+    /// and stay valid until `sync()`.
+    pub unsafe fn rollout_record(&mut self, n_steps: u32, action_seed: u64, action_t0: u64, out: &ffi::Trajectory) {
+        check(ffi::gymrs_rollout_record(self.raw, n_steps, action_seed, action_t0, out));
+    }
+
     /// Wait for everything queued on the engine's stream.
     pub fn sync(&mut self) {
         check(unsafe { ffi::gymrs_sync(self.raw) });

@@ -50,6 +50,18 @@ pub struct MountainCarParams {
     pub _pad: u32,
 }
 
+/// `gymrs_trajectory`: device buffers `[n_steps][..][lane_stride]` filled by `gymrs_rollout_record`.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct Trajectory {
+    pub obs: *mut f32,
+    pub actions: *mut c_void,
+    pub reward: *mut f32,
+    pub done: *mut u8,
+    pub truncated: *mut u8,
+    pub lane_stride: u64,
+}
+
 extern "C" {
     pub fn gymrs_abi_version() -> c_int;
     pub fn gymrs_last_error() -> *const c_char;
@@ -78,6 +90,7 @@ extern "C" {
         use_graph: c_int,
     ) -> c_int;
     pub fn gymrs_rollout(e: *mut GymrsEngine, n_steps: u32, action_seed: u64, action_t0: u64) -> c_int;
+    pub fn gymrs_rollout_record(e: *mut GymrsEngine, n_steps: u32, action_seed: u64, action_t0: u64, out: *const Trajectory) -> c_int;
     pub fn gymrs_sync(e: *mut GymrsEngine) -> c_int;
     pub fn gymrs_get_state(e: *mut GymrsEngine, first: u64, count: u64, host_out: *mut f32) -> c_int;
     pub fn gymrs_set_state(e: *mut GymrsEngine, first: u64, count: u64, host_in: *const f32) -> c_int;

@@ -50,6 +50,7 @@ SIGNATURES = {
     "gymrs_snapshot_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "gymrs_snapshot_save": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "gymrs_snapshot_load": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
+    "gymrs_rollout_record": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "gymrs_rollout": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
     "gymrs_fill_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gymrs_get_tick": (C.c_int, [C.c_void_p, u64p, u64p]),

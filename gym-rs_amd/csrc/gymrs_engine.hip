@@ -633,21 +633,40 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
 
 // The caller loop of the reference's examples (examples/cartpole.rs:15-30: random action, step, reset on
 // done, accumulate the return) fused into one launch; see rollout_kernel.
-gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0)
+static gymrs_status rollout_impl(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0,
+                                 const gymrs_trajectory* rec, const char* who)
 {
-    if (!e) return fail(GYMRS_EINVAL, "gymrs_rollout: NULL engine");
+    if (!e) return fail(GYMRS_EINVAL, std::string(who) + ": NULL engine");
     if (n_steps == 0) return GYMRS_OK;
     HIP_TRY(hipSetDevice(e->device));
     StepArgs a = step_args(e, nullptr);
     a.skip_trunc_store = 0; // the kernel stores the LAST step's flags, whatever the array holds now
     RolloutArgs r;
+    std::memset(&r, 0, sizeof(r));
     r.action_seed = action_seed;
     r.action_t0 = action_t0;
     r.uniform_start = e->uniform_start;
     r.n_steps = n_steps;
     r.n_actions = e->kind == GYMRS_CARTPOLE ? 2u : 3u;
     r.max_torque = e->max_torque;
-    const int vec = e->vec == 8 ? 8 : 4;
+    int vec = e->vec == 8 ? 8 : 4;
+    if (rec) {
+        if (!rec->obs || !rec->actions || !rec->reward || !rec->done)
+            return fail(GYMRS_EINVAL, std::string(who) + ": obs, actions, reward and done buffers are required");
+        if (rec->lane_stride < e->n || rec->lane_stride % 16 != 0)
+            return fail(GYMRS_EINVAL, std::string(who) + ": lane_stride must be >= n_envs and a multiple of 16");
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(rec->obs) | reinterpret_cast<uintptr_t>(rec->actions) |
+                               reinterpret_cast<uintptr_t>(rec->reward) | reinterpret_cast<uintptr_t>(rec->done) |
+                               reinterpret_cast<uintptr_t>(rec->truncated);
+        if (bits % 16 != 0) return fail(GYMRS_EINVAL, std::string(who) + ": trajectory buffers must be 16-byte aligned");
+        r.rec_obs = rec->obs;
+        r.rec_action = rec->actions;
+        r.rec_reward = rec->reward;
+        r.rec_done = rec->done;
+        r.rec_trunc = rec->truncated;
+        r.rec_stride = rec->lane_stride;
+        vec = 4;
+    }
     if (gymrs_status st = prepare_open_sums(e, vec)) return st;
     HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
     for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
@@ -660,6 +679,18 @@ gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_se
     }
     e->n_steps_total += (double)e->n * (double)n_steps;
     return GYMRS_OK;
+}
+
+gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0)
+{
+    return rollout_impl(e, n_steps, action_seed, action_t0, nullptr, "gymrs_rollout");
+}
+
+gymrs_status gymrs_rollout_record(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0,
+                                  const gymrs_trajectory* out)
+{
+    if (!out) return fail(GYMRS_EINVAL, "gymrs_rollout_record: trajectory is NULL");
+    return rollout_impl(e, n_steps, action_seed, action_t0, out, "gymrs_rollout_record");
 }
 
 gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host)

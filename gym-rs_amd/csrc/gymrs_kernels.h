@@ -44,6 +44,13 @@ struct RolloutArgs {
     uint32_t n_steps;
     uint32_t n_actions;     // Discrete(n) envs
     float max_torque;       // Pendulum
+    // gymrs_rollout_record: every step's outputs go to trajectory buffers, row k = step k (NULL = not recorded)
+    float* rec_obs;         // [n_steps][obs_dim][rec_stride]
+    void* rec_action;       // [n_steps][rec_stride] u8 (f32 for Pendulum)
+    float* rec_reward;      // [n_steps][rec_stride]
+    uint8_t* rec_done;      // [n_steps][rec_stride]
+    uint8_t* rec_trunc;     // [n_steps][rec_stride], written with GYMRS_TIME_LIMIT only; may be NULL
+    uint64_t rec_stride;    // lanes per row: >= n, a multiple of 16
 };
 
 struct ResetArgs {

@@ -10,7 +10,10 @@ namespace gymrs {
 // (physics + one Philox block per lane per 4 steps for the actions + the compacted reset pass), not
 // HBM-bound.  Bit-identical to n_steps calls of gymrs_fill_actions + gymrs_step: it calls the same
 // advance_tile, step after step, and leaves the arrays as the last of those steps would.
-template <class Env, int VEC, uint32_t FLAGS, bool FULL>
+// REC (gymrs_rollout_record): additionally every step's observation, action, reward and flags are written to
+// trajectory buffers -- what a random-policy data collection loop keeps.  Then HBM sees 22 B per CartPole
+// lane-step (no state re-read, no launch per step) instead of 38 B + a launch + an action-generation kernel.
+template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool REC>
 __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, const typename Env::Consts& c,
                                               ResetLds<Env, VEC, kBlock>& lds)
 {
@@ -71,6 +74,26 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
             if (a.truncate_all && R::AUTO) ustart = a.tick + 1;
         }
         advance_tile<Env, VEC, FLAGS, FULL, true, kBlock>(a, c, base, d, lds, resets, ret, open, out);
+        if constexpr (REC) {
+            const uint64_t row = (uint64_t)k * r.rec_stride;
+            constexpr int kObs = Env::kHasObsExtra ? 3 : Env::kState;
+            float* obs = r.rec_obs + row * kObs;
+            if constexpr (Env::kHasObsExtra) { // Pendulum: (cos, sin, theta_dot) as store_tile writes them
+                Vec<float, kVec> oc, os;
+#pragma unroll
+                for (int i = 0; i < kVec; ++i) sincosf_(d.st[0].v[i], &os.v[i], &oc.v[i]);
+                store_vec<float, kVec, true>(obs, base, a.n, FULL, oc);
+                store_vec<float, kVec, true>(obs + r.rec_stride, base, a.n, FULL, os);
+                store_vec<float, kVec, true>(obs + 2 * r.rec_stride, base, a.n, FULL, d.st[1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, true>(obs + j * r.rec_stride, base, a.n, FULL, d.st[j]);
+            }
+            store_vec<Action, kVec, true>(static_cast<Action*>(r.rec_action) + row, base, a.n, FULL, d.act);
+            store_vec<float, kVec, true>(r.rec_reward + row, base, a.n, FULL, out.reward);
+            store_vec<uint8_t, kVec, true>(r.rec_done + row, base, a.n, FULL, out.done);
+            if (R::TLIM && r.rec_trunc) store_vec<uint8_t, kVec, true>(r.rec_trunc + row, base, a.n, FULL, out.trunc);
+        }
     }
     store_tile<Env, VEC, FLAGS, FULL, true>(a, base, d, out);
     if (R::STATS && (threadIdx.x & 63u) == 0) {
@@ -82,22 +105,30 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
     }
 }
 
-template <class Env, int VEC, uint32_t FLAGS>
+template <class Env, int VEC, uint32_t FLAGS, bool REC>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(16 / VEC, 16 / VEC))) void rollout_kernel(
     const StepArgs a, const RolloutArgs r, const typename Env::Consts c)
 {
     constexpr int LPB = kBlock * VEC;
     __shared__ ResetLds<Env, VEC, kBlock> lds;
     if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= a.n) // wave-uniform, see step_kernel
-        rollout_block<Env, VEC, FLAGS, true>(a, r, c, lds);
+        rollout_block<Env, VEC, FLAGS, true, REC>(a, r, c, lds);
     else
-        rollout_block<Env, VEC, FLAGS, false>(a, r, c, lds);
+        rollout_block<Env, VEC, FLAGS, false, REC>(a, r, c, lds);
 }
 
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t rollout_one(const StepArgs& a, const RolloutArgs& r, const void* consts, hipStream_t stream)
 {
-    hipLaunchKernelGGL((rollout_kernel<Env, VEC, FLAGS>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a, r,
+    if constexpr (VEC == 4) { // the recording variant exists at 4 lanes per work-item only
+        if (r.rec_obs) {
+            hipLaunchKernelGGL((rollout_kernel<Env, VEC, FLAGS, true>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a, r,
+                               *static_cast<const typename Env::Consts*>(consts));
+            return hipGetLastError();
+        }
+    }
+    if (r.rec_obs) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((rollout_kernel<Env, VEC, FLAGS, false>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a, r,
                        *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }

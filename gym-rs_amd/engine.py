@@ -59,6 +59,12 @@ class PendulumParams(C.Structure):
     ]
 
 
+class Trajectory(C.Structure):
+    """``gymrs_trajectory`` (include/gymrs_amd.h)."""
+    _fields_ = [("obs", C.c_void_p), ("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("truncated", C.c_void_p), ("lane_stride", C.c_uint64)]
+
+
 _PARAMS = {CARTPOLE: CartPoleParams, MOUNTAIN_CAR: MountainCarParams, PENDULUM: PendulumParams}
 _STATE_DIM = {CARTPOLE: 4, MOUNTAIN_CAR: 2, PENDULUM: 2}
 _OBS_DIM = {CARTPOLE: 4, MOUNTAIN_CAR: 2, PENDULUM: 3}
@@ -299,6 +305,16 @@ class BatchedEngine:
         ``fill_actions(buf, action_seed, action_t0 + k); step(buf)`` for k in range(n_steps), bit for bit
         (the caller loop of examples/cartpole.rs:15-30)."""
         _check(self._lib, self._lib.gymrs_rollout(self._h, int(n_steps), int(action_seed), int(action_t0)))
+
+    def rollout_record(self, n_steps: int, action_seed: int, action_t0: int, *, obs: int, actions: int, reward: int,
+                       done: int, truncated: int = 0, lane_stride: Optional[int] = None) -> None:
+        """``rollout`` that also keeps the trajectory.  The arguments are device addresses of buffers laid out
+        ``obs[n_steps][obs_dim][lane_stride]`` (f32), ``actions/reward/done/truncated[n_steps][lane_stride]``;
+        ``lane_stride`` defaults to n_envs rounded up to a multiple of 16."""
+        stride = int(lane_stride) if lane_stride is not None else (self.n_envs + 15) // 16 * 16
+        traj = Trajectory(C.c_void_p(obs), C.c_void_p(actions), C.c_void_p(reward), C.c_void_p(done),
+                          C.c_void_p(truncated or None), stride)
+        _check(self._lib, self._lib.gymrs_rollout_record(self._h, int(n_steps), int(action_seed), int(action_t0), C.byref(traj)))
 
     def fill_actions(self, actions_dev: int, seed: int, t: int) -> None:
         _check(self._lib, self._lib.gymrs_fill_actions(self._h, C.c_void_p(actions_dev), int(seed), int(t)))

@@ -155,6 +155,26 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
  * loop; the intermediate observations are never materialised, which is why this is a separate entry point and
  * not what bench.py's headline measures.  VALU-bound instead of HBM-bound. */
 gymrs_status gymrs_rollout(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0);
+/* gymrs_rollout that also keeps the trajectory: what a random-policy data-collection loop around Env::step stores
+ * (examples/cartpole.rs:15-30 with the observation, action, reward and done of every step kept).  Row k of each
+ * buffer is step k; a row holds lane_stride lanes (>= n_envs, a multiple of 16); all buffers are device memory,
+ * 16-byte aligned:
+ *   obs      [n_steps][obs_dim][lane_stride] f32   observation AFTER the step (a re-armed lane shows its fresh state,
+ *                                                  exactly what gymrs_obs_ptrs would show after that step)
+ *   actions  [n_steps][lane_stride] u8 (f32 for Pendulum)   the action taken
+ *   reward   [n_steps][lane_stride] f32,  done [n_steps][lane_stride] u8
+ *   truncated[n_steps][lane_stride] u8    written with GYMRS_TIME_LIMIT only; may be NULL
+ * Everything else is as gymrs_rollout (engine arrays, statistics and tick end up identical). */
+typedef struct {
+    float* obs;
+    void* actions;
+    float* reward;
+    uint8_t* done;
+    uint8_t* truncated;
+    uint64_t lane_stride;
+} gymrs_trajectory;
+gymrs_status gymrs_rollout_record(gymrs_engine* e, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0,
+                                  const gymrs_trajectory* out);
 /* `Env: Clone + Serialize` (core.rs:25; the serde-visible fields of cartpole.rs:51-87 / mountain_car.rs:46-80).
  * gymrs_engine_clone: a second engine (own stream, same device) with a deep copy of everything a step can observe:
  * lane state, episode bookkeeping, statistics, physics constants, reset box and the RNG position (seed, tick).

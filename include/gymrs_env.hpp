@@ -108,6 +108,11 @@ public:
     {
         check(gymrs_rollout(e_, n_steps, action_seed, action_t0));
     }
+    // the same loop keeping every step's (observation, action, reward, done) in device buffers
+    void rollout_record(std::uint32_t n_steps, std::uint64_t action_seed, std::uint64_t action_t0, const gymrs_trajectory& out)
+    {
+        check(gymrs_rollout_record(e_, n_steps, action_seed, action_t0, &out));
+    }
     std::array<double, 4> stats() // {sum_return, sum_length, n_episodes, n_steps}
     {
         std::array<double, 4> out{};

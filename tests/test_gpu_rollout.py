@@ -147,3 +147,61 @@ def test_pendulum_returns_survive_a_change_of_launch_shape(gymrs, twin):
     assert gs[0] == pytest.approx(ts[0], rel=1e-6)
     assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
     eng.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("flags", [A | S, A | S | T, T])
+def test_rollout_record_keeps_what_per_step_stepping_shows(gymrs, kind, flags):
+    """gymrs_rollout_record: row k of the trajectory = what the per-step API shows after step k (observation incl.
+    fresh states of re-armed lanes, action, reward, done, truncated), and the engines end up identical."""
+    n, steps, t0 = 5001, 37, 5
+    stride = 5008
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 9
+    rec = gymrs.BatchedEngine(kind, n, flags=flags, params=p, global_env_offset=64)
+    ref = gymrs.BatchedEngine(kind, n, flags=flags, params=p, global_env_offset=64)
+    rec.reset(seed=12)
+    ref.reset(seed=12)
+    obs_dim = rec.obs_dim
+    act_dtype = torch.float32 if kind == 2 else torch.uint8
+    dev = "cuda:0"
+    obs = torch.full((steps, obs_dim, stride), float("nan"), dtype=torch.float32, device=dev)
+    act = torch.zeros((steps, stride), dtype=act_dtype, device=dev)
+    rew = torch.full((steps, stride), float("nan"), dtype=torch.float32, device=dev)
+    done = torch.full((steps, stride), 9, dtype=torch.uint8, device=dev)
+    trunc = torch.full((steps, stride), 9, dtype=torch.uint8, device=dev)
+    rec.rollout_record(steps, 3, t0, obs=obs.data_ptr(), actions=act.data_ptr(), reward=rew.data_ptr(), done=done.data_ptr(),
+                       truncated=trunc.data_ptr(), lane_stride=stride)
+    rec.sync()
+    obs_h, act_h, rew_h, done_h, trunc_h = (x.cpu().numpy() for x in (obs, act, rew, done, trunc))
+    buf = torch.empty(n, dtype=act_dtype, device=dev)
+    for k in range(steps):
+        ref.fill_actions(buf.data_ptr(), seed=3, t=t0 + k)
+        ref.step(buf.data_ptr())
+        ref.sync()
+        assert np.array_equal(act_h[k, :n], buf.cpu().numpy()), k
+        assert np.array_equal(obs_h[k, :, :n].view(np.uint32), ref.get_obs().view(np.uint32)), k
+        r, d, tr = ref.get_step_result()
+        assert np.array_equal(rew_h[k, :n].view(np.uint32), r.view(np.uint32)), k
+        assert np.array_equal(done_h[k, :n], d), k
+        if flags & T:
+            assert np.array_equal(trunc_h[k, :n], tr), k
+    assert np.isnan(obs_h[:, :, n:]).all() and (done_h[:, n:] == 9).all()  # the padding of a row is never written
+    assert np.array_equal(rec.get_state().view(np.uint32), ref.get_state().view(np.uint32))
+    assert np.array_equal(rec.stats(), ref.stats()) and rec.tick() == ref.tick()
+    rec.close()
+    ref.close()
+
+
+def test_rollout_record_rejects_bad_buffers(gymrs):
+    with gymrs.BatchedEngine(0, 100, flags=A) as eng:
+        eng.reset(seed=1)
+        good = torch.zeros(4 * 112 * 4, dtype=torch.float32, device="cuda:0").data_ptr()
+        with pytest.raises(gymrs.GymrsError):
+            eng.rollout_record(1, 1, 0, obs=good, actions=good, reward=good, done=good, lane_stride=96)   # < n
+        with pytest.raises(gymrs.GymrsError):
+            eng.rollout_record(1, 1, 0, obs=good, actions=good, reward=good, done=good, lane_stride=104)  # not a multiple of 16
+        with pytest.raises(gymrs.GymrsError):
+            eng.rollout_record(1, 1, 0, obs=good + 4, actions=good, reward=good, done=good, lane_stride=112)  # misaligned
+        with pytest.raises(gymrs.GymrsError):
+            eng.rollout_record(1, 1, 0, obs=good, actions=0, reward=good, done=good, lane_stride=112)  # missing buffer

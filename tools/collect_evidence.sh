@@ -16,6 +16,9 @@ done
 for env in cartpole mountain_car pendulum; do
     python bench.py --env $env --rollout 128 --steps 2048 --warmup 256 --cpu-seconds 0 > "$OUT/${TAG}_bench_rollout_${env}.json" 2>/dev/null
 done
+for env in cartpole mountain_car pendulum; do
+    python bench.py --env $env --rollout 128 --record --steps 1024 --warmup 128 --cpu-seconds 0 > "$OUT/${TAG}_bench_rollout_recorded_${env}.json" 2>/dev/null
+done
 for n in 1024 16384 131072; do
     for g in "" "--graph"; do
         python bench.py --n-envs $n --steps 4000 --warmup 400 --cpu-seconds 0 $g 2>/dev/null
