@@ -136,18 +136,26 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
     a.ep_start[lane] = (uint32_t)(a.tick + 1); // = the epoch the statistics are measured from
 }
 
-// Random-policy actions (examples/cartpole.rs:19 `rng.gen_range(0..=1)`), Philox stream 1.
+// Random-policy actions (examples/cartpole.rs:19 `rng.gen_range(0..=1)`), Philox stream 1.  A work-item serves one
+// aligned group of four global env ids: they share one Philox block (gymrs_philox.h).
 template <class Env>
 __global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Action* out, uint64_t n, uint64_t gid0,
                                                               uint64_t seed, uint64_t t, uint32_t n_actions,
                                                               float max_torque)
 {
-    const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (lane >= n) return;
-    if constexpr (sizeof(typename Env::Action) == 1) {
-        out[lane] = action_discrete(seed, gid0 + lane, t, n_actions);
-    } else {
-        out[lane] = uniform_between(action_word(seed, gid0 + lane, t), -max_torque, max_torque);
+    constexpr bool kDiscrete = sizeof(typename Env::Action) == 1;
+    const uint64_t group = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t first_gid = (gid0 & ~3ull) + 4 * group;
+    if (first_gid >= gid0 + n) return;
+    const u32x4 blk = action_block(seed, first_gid, kDiscrete ? (t >> 1) : t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t gid = first_gid + j;
+        if (gid < gid0 || gid >= gid0 + n) continue; // the shard need not start or end on a multiple of 4
+        if constexpr (kDiscrete)
+            out[gid - gid0] = discrete_from_word(blk.v[j], t, n_actions);
+        else
+            out[gid - gid0] = uniform_between(blk.v[j], -max_torque, max_torque);
     }
 }
 
@@ -313,7 +321,8 @@ hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, u
                                float max_torque, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
-    const uint32_t grid = (uint32_t)((n + kBlock - 1) / kBlock);
+    const uint64_t groups = (n + (gid0 & 3u) + 3) / 4; // aligned groups of four global ids that touch the shard
+    const uint32_t grid = (uint32_t)((groups + kBlock - 1) / kBlock);
     switch (kind) {
     case GYMRS_CARTPOLE:
         hipLaunchKernelGGL((fill_actions_kernel<CartPoleT>), dim3(grid), dim3(kBlock), 0, stream,
