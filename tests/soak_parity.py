@@ -1,7 +1,7 @@
 """One-off long-run parity check (too slow for the test-suite: the CPU twin needs ~40 s): 2*10^5 steps of every env
 through the fused rollout kernel against the f32 twin stepped one by one -- global env ids beyond 2^32, a seed
 beyond 2^63, time limit + auto-reset + statistics on.  State bits and integer statistics must be identical.
-    gpurun -- 'python tools/soak.py'
+    gpurun -- 'python tests/soak_parity.py'
 """
 import importlib
 import sys
