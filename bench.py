@@ -1,15 +1,24 @@
 #!/usr/bin/env python
 """bench.py — env-steps/sec of the batched stepper (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # or under an external launcher
 
 A "step" is ONE Env::step() of every lane of the workload = one launch of the step kernel over the
 rank's shard (auto-reset and statistics on).  Workload at N=1: BASELINE.json configs[1], CartPole-v1
 at 2^20 parallel envs, f32.  At N>1 every rank holds 2^20 lanes (weak scaling; configs[4] at N=8 is
-2^23 lanes) with global env ids rank*2^20+i and no data-path collective; the only collective is one
-RCCL all-reduce of the 4 statistics doubles at the end of the timed region.
+2^23 lanes) with global env ids rank*2^20+i and no data-path collective; the only collective of the
+path is one RCCL all-reduce of the 4 statistics doubles, taken AFTER the timed region (its cost is
+reported separately as stats_readout_us).
+
+Timing (">= 5 repetitions, report the median"): after W warm-up steps the bench times R = 5
+repetitions.  One repetition = P back-to-back passes of EXACTLY K steps, bracketed by
+barrier + torch.cuda.synchronize() on both sides (wall clock) and by HIP events on the engine's stream
+(kernel time); P is chosen once so that a repetition lasts >= ~5 ms -- K = 20 launches of a 7 us kernel
+are 0.14 ms, less than the host's own synchronisation jitter.  Per repetition the MAX over ranks is taken,
+then the MEDIAN over repetitions; ms_per_step = that time / (P * K), value = all lanes * P * K / that time.
+Nothing but the K-step passes sits inside a timed repetition.
 
 Inputs are resident in HBM before the timed region: the state arrays, and a ring of pre-generated
 random-policy action buffers (the `rng.gen_range(0..=1)` of examples/cartpole.rs:19, produced on the
@@ -20,9 +29,12 @@ Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how each field is o
 from __future__ import annotations
 
 import argparse
+import hashlib
 import importlib
 import json
+import math
 import os
+import statistics
 import sys
 import time
 from pathlib import Path
@@ -31,12 +43,27 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 ENVS = {
-    # name: (kind, default lanes per GPU, algorithmic bytes per env-step, workload label)
-    "cartpole": (0, 1 << 20, 38, "CartPole-v1 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
-    "mountain_car": (1, 1 << 20, 22, "MountainCar-v0 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
-    "pendulum": (2, 1 << 22, 37, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, auto-reset, 200-step time limit, random policy"),
+    # name: (kind, default lanes per GPU, algorithmic bytes per env-step read / written, workload label)
+    "cartpole": (0, 1 << 20, 17, 21, "CartPole-v1 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
+    "mountain_car": (1, 1 << 20, 9, 13, "MountainCar-v0 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
+    "pendulum": (2, 1 << 22, 12, 25, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, auto-reset, 200-step time limit, random policy"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+# VALU issue roofline of the fused rollout kernel: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
+MIN_REPETITION_SECONDS = 5e-3
+REPETITIONS = 5
+
+
+def kernel_source_sha16() -> str:
+    """Identifies the kernels a PMC figure under profiles/ was collected with: traffic measured with other
+    sources is stale and must not be printed beside a new kernel's time."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "gym-rs_amd" / "csrc").glob("gymrs_*")):
+        if p.suffix in (".h", ".hip"):
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(kind: int, target_seconds: float):
@@ -83,14 +110,14 @@ def cpu_baseline(kind: int, target_seconds: float):
     }
 
 
-def main() -> int:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5000)
-    ap.add_argument("--warmup", type=int, default=500)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--env", choices=sorted(ENVS), default="cartpole")
     ap.add_argument("--n-envs", type=int, default=0, help="lanes per GPU (default: the BASELINE config)")
-    ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4, 8, 16); 0 = engine default")
+    ap.add_argument("--vec", type=int, default=0, help="lanes per work-item (4 or 8); 0 = engine default")
     ap.add_argument("--nt", type=int, default=0, help="memory hint: 0 auto, 1 always non-temporal, 2 never")
     ap.add_argument("--action-buffers", type=int, default=32)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length; 0 disables it")
@@ -100,63 +127,202 @@ def main() -> int:
     ap.add_argument("--record", action="store_true",
                     help="with --rollout: gymrs_rollout_record, i.e. every step's observation/action/reward/done is kept")
     ap.add_argument("--graph", action="store_true", help="replay captured HIP graphs (pays for small batches only)")
-    ap.add_argument("--native-rccl", action="store_true", help="all-reduce through the C ABI's RCCL path")
-    args = ap.parse_args()
+    ap.add_argument("--torch-allreduce", action="store_true",
+                    help="sum the statistics with torch.distributed instead of the C ABI's own RCCL communicator")
+    ap.add_argument("--native-rccl", action="store_true", help="(default since round 2; kept for old command lines)")
+    ap.add_argument("--repetitions", type=int, default=REPETITIONS)
+    ap.add_argument("--no-probe", action="store_true", help="skip the in-process copy-kernel probe (roofline.peak_measured)")
+    ap.add_argument("--pmc-traffic", action="store_true",
+                    help="N=1: also run two short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) and "
+                         "report the traffic they measure (and refresh profiles/pmc_traffic.json)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="TEST ONLY: ranks share GPUs (rank r -> device r %% device_count) and meet over gloo, so that the "
+                         "N>1 code path (spawner, global env offsets, aggregation) runs on a 1-GPU box; not a benchmark")
+    return ap.parse_args(argv)
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            return 2
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the stepper has no CPU fallback", file=sys.stderr)
-        return 2
-    torch.cuda.set_device(local_rank)
-    force_dist = os.environ.get("GYMRS_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
-    dist_on = world > 1 or (force_dist and "RANK" in os.environ)
-    if dist_on:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+class HipBackend:
+    """The GPU side of one rank: engines from the C ABI, device action ring, HIP events on the engine's stream."""
 
+    name = "hip"
+
+    def __init__(self, args, info):
+        import torch
+
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py: no GPU visible; the stepper has no CPU fallback")
+        n_dev = torch.cuda.device_count()
+        self.oversubscribed = bool(args.oversubscribe and info.world > n_dev)
+        self.dev_index = info.local_rank % n_dev if args.oversubscribe else info.local_rank
+        if self.dev_index >= n_dev:
+            raise SystemExit(f"bench.py: rank {info.rank} needs GPU {self.dev_index} but only {n_dev} are visible "
+                             f"(one process per GPU)")
+        torch.cuda.set_device(self.dev_index)
+        self.device = torch.device("cuda", self.dev_index)
+        # RCCL refuses two ranks on one device: an oversubscribed TEST run meets over gloo instead
+        self.collective_backend = "gloo" if self.oversubscribed else "nccl"
+        self.gymrs = importlib.import_module("gym-rs_amd")
+
+    def make_engine(self, kind, n, offset, flags, vec):
+        return self.gymrs.BatchedEngine(kind, n, global_env_offset=offset, device=self.dev_index, flags=flags,
+                                        lanes_per_thread=vec or None)
+
+    def make_action_ring(self, eng, n, nbuf, is_float):
+        torch = self.torch
+        ring = torch.empty((nbuf, n), dtype=torch.float32 if is_float else torch.uint8, device=self.device)
+        torch.cuda.synchronize()
+        for b in range(nbuf):
+            eng.fill_actions(ring[b].data_ptr(), seed=1, t=b)
+        return ring.data_ptr(), ring.stride(0) * ring.element_size(), ring
+
+    def stream_of(self, eng):
+        return self.torch.cuda.ExternalStream(eng.stream, device=self.device)
+
+    def mark(self, stream):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def copy_probe(self, read_bytes, write_bytes, launches, nt):
+        import ctypes as C
+
+        lib = self.gymrs.load_library()
+        out = C.c_double()
+        st = lib.gymrs_copy_probe(self.dev_index, int(read_bytes), int(write_bytes), int(launches), int(nt), C.byref(out))
+        return out.value if st == 0 else None
+
+    def trajectory_buffers(self, eng, n, rollout, is_float):
+        torch = self.torch
+        rs = (n + 15) // 16 * 16
+        rec = {"obs": torch.empty((rollout, eng.obs_dim, rs), dtype=torch.float32, device=self.device),
+               "actions": torch.empty((rollout, rs), dtype=torch.float32 if is_float else torch.uint8, device=self.device),
+               "reward": torch.empty((rollout, rs), dtype=torch.float32, device=self.device),
+               "done": torch.empty((rollout, rs), dtype=torch.uint8, device=self.device)}
+        torch.cuda.synchronize()
+        return rec
+
+
+def choose_passes(seconds_per_pass: float, min_seconds: float = MIN_REPETITION_SECONDS) -> int:
+    """Passes of K steps per timed repetition so that a repetition lasts at least min_seconds."""
+    if seconds_per_pass <= 0:
+        return 1
+    return max(1, int(math.ceil(min_seconds / seconds_per_pass)))
+
+
+def timed_repetitions(backend, coll, stream, run_pass, passes, repetitions):
+    """R repetitions of `passes` x run_pass(); per repetition the MAX over ranks of (wall seconds, event ms)."""
+    walls, kernels = [], []
+    for _ in range(repetitions):
+        coll.barrier()
+        backend.sync()
+        t0 = time.perf_counter()
+        m0 = backend.mark(stream)
+        for _ in range(passes):
+            run_pass()
+        m1 = backend.mark(stream)
+        backend.sync()
+        t1 = time.perf_counter()
+        coll.barrier()
+        wall, kms = coll.max([t1 - t0, backend.elapsed_ms(m0, m1)])
+        walls.append(wall)
+        kernels.append(kms)
+    return walls, kernels
+
+
+def load_pmc(name: str, env: str, sha: str):
+    """A committed PMC figure, only if it was collected with the kernels that are running now."""
+    path = ROOT / "profiles" / name
+    try:
+        data = json.loads(path.read_text())
+    except Exception:
+        return None, f"profiles/{name} missing"
+    if data.get("kernel_source_sha16") != sha:
+        return None, (f"profiles/{name} was collected with other kernel sources (sha {data.get('kernel_source_sha16')}, "
+                      f"now {sha}): dropped as stale; refresh with bench.py --pmc-traffic")
+    return data.get(env), None
+
+
+def measure_pmc_traffic(args, env_name: str, sha: str):
+    """Two short rocprofv3 --pmc passes of this very command (one counter per pass, counters only), read back from the
+    rocpd databases; FETCH_SIZE doubled as the guide's gfx950 correction for wide coalesced reads prescribes."""
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    out = {}
+    note = None
+    with tempfile.TemporaryDirectory(prefix="gymrs_pmc_", dir="/tmp") as tmp:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = Path(tmp) / ctr
+            cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
+                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--repetitions", "2"]
+            if args.n_envs:
+                cmd += ["--n-envs", str(args.n_envs)]
+            if args.vec:
+                cmd += ["--vec", str(args.vec)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            dbs = list(d.rglob("*_results.db"))
+            if res.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {res.returncode}): {res.stderr[-300:]}"
+            c = sqlite3.connect(str(dbs[0]))
+            r = c.execute("select count(*), avg(value) from counters_collection where kernel_name like '%step_kernel%' "
+                          "and counter_name = ?", (ctr,)).fetchone()
+            out[ctr] = {"launches": r[0], "avg_kb": r[1]}
+    fetch = 2.0 * out["FETCH_SIZE"]["avg_kb"] * 1024.0
+    write = out["WRITE_SIZE"]["avg_kb"] * 1024.0
+    rec = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "raw": out,
+           "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported"}
+    path = ROOT / "profiles" / "pmc_traffic.json"
+    try:
+        data = json.loads(path.read_text())
+        if data.get("kernel_source_sha16") != sha:
+            data = {}
+    except Exception:
+        data = {}
+    data["kernel_source_sha16"] = sha
+    data[env_name] = rec
+    try:
+        path.write_text(json.dumps(data, indent=1))
+    except Exception as exc:  # read-only checkout: the figure is still reported
+        note = f"could not refresh profiles/pmc_traffic.json: {exc}"
+    return rec, note
+
+
+def run_rank(args, info, backend, make_collective=None):
+    """Everything one rank does.  Returns the result dict on rank 0, None elsewhere.  `backend` supplies engines,
+    action rings, timers (HipBackend here; tests/test_sharded_cpu.py passes a CPU stand-in built on the f32 twin,
+    so that this very function -- sharding, repetitions, max-over-ranks, the statistics all-reduce, the line that is
+    printed -- runs with world_size 2 over gloo)."""
     gymrs = importlib.import_module("gym-rs_amd")
-    kind, n_default, bytes_per_step, workload = ENVS[args.env]
+    sharded = gymrs.sharded
+    kind, n_default, bytes_read, bytes_written, workload = ENVS[args.env]
+    bytes_per_step = bytes_read + bytes_written
     n = args.n_envs or n_default
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
     if args.env == "pendulum":
         flags |= gymrs.TIME_LIMIT  # it never terminates: episodes end by the 200-step time limit only
-    eng = gymrs.BatchedEngine(kind, n, global_env_offset=rank * n, device=local_rank, flags=flags,
-                              lanes_per_thread=args.vec or None)
+    force_dist = os.environ.get("GYMRS_BENCH_FORCE_DIST") == "1"  # exercise the collective path with one rank
+    coll = (make_collective or sharded.Collective)(info, backend.collective_backend, getattr(backend, "device", None), force=force_dist)
+    run = sharded.ShardedRun(info, n, coll, lambda off, cnt: backend.make_engine(kind, cnt, off, flags, args.vec))
+    eng = run.engine
     if args.nt:
         eng.set_tuning(args.vec or 4, args.nt)
-    stream = torch.cuda.ExternalStream(eng.stream, device=local_rank)
-
-    # synthetic inputs, resident in HBM before the timed region
-    act_dtype = torch.float32 if args.env == "pendulum" else torch.uint8
+    stream = backend.stream_of(eng)
+    is_float = args.env == "pendulum"
     nbuf = max(1, args.action_buffers)
-    actions = torch.empty((nbuf, n), dtype=act_dtype, device=f"cuda:{local_rank}")
-    torch.cuda.synchronize()
-    for b in range(nbuf):
-        eng.fill_actions(actions[b].data_ptr(), seed=1, t=b)
-    stride = actions.stride(0) * actions.element_size()
+    act_ptr, act_stride, _ring = backend.make_action_ring(eng, n, nbuf, is_float)
     eng.reset(seed=0)
+    rec = backend.trajectory_buffers(eng, n, args.rollout, is_float) if (args.rollout and args.record) else None
 
-    rec = None
-    if args.rollout and args.record:
-        rs = (n + 15) // 16 * 16
-        dev = f"cuda:{local_rank}"
-        rec = {"obs": torch.empty((args.rollout, eng.obs_dim, rs), dtype=torch.float32, device=dev),
-               "actions": torch.empty((args.rollout, rs), dtype=act_dtype, device=dev),
-               "reward": torch.empty((args.rollout, rs), dtype=torch.float32, device=dev),
-               "done": torch.empty((args.rollout, rs), dtype=torch.uint8, device=dev)}
-        torch.cuda.synchronize()
-
-    def run(k):
+    def run_steps(k):
         if args.rollout:
             done = 0
             while done < k:
@@ -168,75 +334,57 @@ def main() -> int:
                     eng.rollout(r, action_seed=1, action_t0=done)
                 done += r
         else:
-            eng.step_many(actions.data_ptr(), stride, nbuf, k, use_graph=args.graph)
+            eng.step_many(act_ptr, act_stride, nbuf, k, use_graph=args.graph)
 
-    run(args.warmup)
+    # ---- warm-up, communicator set-up, calibration: all outside the timed repetitions ----
+    run_steps(args.warmup)
     eng.sync()
-    eng.stats_clear()
-    if args.native_rccl and dist_on:
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        eng.comm_init(world, rank, uid[0])
-
-    if dist_on and not args.native_rccl:
-        # RCCL builds its communicator lazily on the first collective: do one outside the timed region
-        dist.all_reduce(torch.zeros(4, dtype=torch.float64, device=f"cuda:{local_rank}"))
-    elif dist_on:
-        eng.allreduce_stats()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
+    # (an oversubscribed TEST run cannot use RCCL at all: it refuses two ranks on one device)
+    allreduce_path = run.setup_stats_allreduce(prefer_native=not (args.torch_allreduce or getattr(backend, "oversubscribed", False)))
+    if coll.active:
+        run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
+    backend.sync()
     t0 = time.perf_counter()
-    ev0.record(stream)
-    run(args.steps)
-    ev1.record(stream)
-    if dist_on:
-        if args.native_rccl:
-            total = eng.allreduce_stats()
-        else:
-            st = torch.tensor(eng.stats(), dtype=torch.float64, device=f"cuda:{local_rank}")
-            dist.all_reduce(st)  # RCCL over xGMI: 32 bytes per rank
-            total = st.cpu().numpy()
-    else:
-        total = eng.stats()
-    eng.sync()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    t1 = time.perf_counter()
+    run_steps(args.steps)
+    backend.sync()
+    passes = choose_passes(time.perf_counter() - t0)
+    if os.environ.get("GYMRS_BENCH_PASSES"):  # tests pin the amount of work to compare two runs' statistics
+        passes = max(1, int(os.environ["GYMRS_BENCH_PASSES"]))
+    passes = int(coll.max([passes])[0])  # every rank times the same work
+    eng.stats_clear()
 
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1)  # HIP events on the engine's stream around the K launches
-    if dist_on:
-        tmax = torch.tensor([wall, kernel_ms], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall, kernel_ms = float(tmax[0]), float(tmax[1])
-    total_steps = float(total[3])
-    assert total_steps == float(n) * args.steps * world, (total_steps, n, args.steps, world)
+    # ---- the timed region ----
+    reps = max(1, args.repetitions)
+    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps), passes, reps)
 
-    if rank == 0:
-        value = total_steps / wall
-        launch_us = kernel_ms * 1e3 / args.steps
+    # ---- read-out, after the clock: statistics all-reduce (the only collective of the path) ----
+    backend.sync()
+    t0 = time.perf_counter()
+    total = run.allreduce_stats()
+    stats_readout_us = (time.perf_counter() - t0) * 1e6
+    steps_per_lane = args.steps * passes * reps
+    run.check_total_steps(total, steps_per_lane)
+    per_rank = coll.gather_to_root({"rank": info.rank, "device": getattr(backend, "dev_index", None),
+                                    "global_env_offset": run.offset,
+                                    "launch_us": statistics.median(kernels) * 1e3 / (args.steps * passes)})
+    out = None
+    if info.is_root:
+        wall = statistics.median(walls)
+        kernel_ms = statistics.median(kernels)
+        steps_timed = args.steps * passes
+        value = run.job_rate(steps_timed, wall)
+        launch_us = kernel_ms * 1e3 / steps_timed
         achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tr_file = ROOT / "profiles" / "pmc_traffic.json"
-        if tr_file.exists():
-            try:
-                traffic = json.loads(tr_file.read_text()).get(args.env, {}).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        sha = kernel_source_sha16()
         out = {
             "metric": "env-steps/sec (whole node), CartPole-v1 @ 2^20 envs per MI355X" if args.env == "cartpole"
                       else f"env-steps/sec (whole node), {args.env}",
             "value": value,
             "unit": "env-steps/s",
-            "n_gpus": world,
+            "n_gpus": info.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / args.steps,
+            "ms_per_step": wall * 1e3 / steps_timed,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -246,44 +394,134 @@ def main() -> int:
                 "workload": workload,
                 "env": args.env,
                 "lanes_per_gpu": n,
-                "total_lanes": n * world,
+                "total_lanes": run.total_lanes,
                 "flags": "|".join(nm for bit, nm in ((1, "AUTO_RESET"), (2, "TRACK_STATS"), (4, "TIME_LIMIT")) if flags & bit),
                 "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
                 "hip_graph": bool(args.graph),
-                "parallelism": f"lane-sharded x{world}, no data-path collective; 1 RCCL all-reduce of 4 f64 per run",
+                "parallelism": f"lane-sharded x{info.world}, no data-path collective; 1 all-reduce of 4 f64 per run, after the clock",
+                "stats_allreduce": allreduce_path,
             },
+            "timing": {
+                "repetitions": reps,
+                "passes_per_repetition": passes,
+                "steps_per_repetition": steps_timed,
+                "wall_ms_per_repetition": [w * 1e3 for w in walls],
+                "event_ms_per_repetition": kernels,
+                "statistic": "median over repetitions of the max over ranks",
+                "stats_readout_us": stats_readout_us,
+            },
+            "ranks": per_rank,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": traffic,
-                "kernel": "step_kernel<%s, 4, flags=%d>" % (args.env, flags),
+                "traffic": None,
+                "kernel": "step_kernel<%s, %d, flags=%d>" % (args.env, args.vec or 4, flags),
                 "bytes_per_env_step": bytes_per_step,
                 "bytes_per_launch": n * bytes_per_step,
                 "launch_us": launch_us,
-                "how": "HIP events on the engine stream around the K timed launches / K (includes inter-kernel gaps)",
+                "how": "HIP events on the engine stream around P*K back-to-back launches / (P*K), median of the repetitions "
+                       "(includes the inter-kernel gaps); rank 0's lanes",
+                "kernel_source_sha16": sha,
             },
             "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},
         }
-        if args.rollout:
-            # the fused kernel touches HBM once per launch of R steps: it is VALU-bound, the HBM roofline of the
-            # per-step kernel does not apply and is not claimed
+        if run.allreduce_note:
+            out["config"]["stats_allreduce_note"] = run.allreduce_note
+        if getattr(backend, "oversubscribed", False):
+            out["oversubscribed"] = "TEST RUN: ranks share GPUs and meet over gloo; value is not a benchmark result"
+        roof = out["roofline"]
+        if not args.rollout:
+            # traffic: measured by this run (--pmc-traffic) or the committed figure if it belongs to these kernels
+            traffic, note = (None, None)
+            if args.pmc_traffic and info.world == 1 and backend.name == "hip":
+                rec_t, note = measure_pmc_traffic(args, args.env, sha)
+                traffic = rec_t["bytes_per_launch"] if rec_t else None
+                roof["traffic_source"] = "rocprofv3 --pmc passes run by this command"
+            else:
+                rec_t, note = load_pmc("pmc_traffic.json", args.env, sha)
+                if rec_t and (args.n_envs in (0, n_default)) and not args.vec:
+                    traffic = rec_t["bytes_per_launch"]
+                    roof["traffic_source"] = "profiles/pmc_traffic.json (same kernel sources)"
+            roof["traffic"] = traffic
+            if note:
+                roof["traffic_note"] = note
+            if traffic:
+                # what is MOVED next to what is COUNTED: MountainCar elides its constant reward store, Pendulum's theta_dot
+                # observation column aliases the state column
+                roof["achieved_moved"] = traffic / (launch_us * 1e-6) / 1e9
+                roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
+            if not args.no_probe and hasattr(backend, "copy_probe"):
+                # the same box, the same process: what a plain copy gets (a) on HBM, (b) at this launch's footprint
+                nt = 1 if n * bytes_per_step <= (48 << 20) else 0
+                big = 1 << 30
+                us_big = backend.copy_probe(big, big, 20, 0)
+                us_same = backend.copy_probe(n * bytes_read // 16 * 16, n * bytes_written // 16 * 16, 500, nt)
+                if us_big and us_same:
+                    roof["peak_measured"] = {
+                        "hbm_copy_GBps": 2 * big / (us_big * 1e-6) / 1e9,
+                        "hbm_copy": "1 GiB read + 1 GiB written per launch (beyond the 256 MiB Infinity Cache), dwordx4 copy kernel",
+                        "same_footprint_copy_us": us_same,
+                        "same_footprint_copy_GBps": n * bytes_per_step / (us_same * 1e-6) / 1e9,
+                        "same_footprint_copy": f"{bytes_read} B read + {bytes_written} B written per lane, {n} lanes per launch, back-to-back "
+                                               "launches: the floor of a step launch of this size (launch cost included)",
+                    }
+                    roof["frac_of_measured_hbm_copy"] = achieved / roof["peak_measured"]["hbm_copy_GBps"]
+                    roof["frac_of_same_footprint_copy"] = us_same / launch_us
+        else:
+            # The fused kernel touches HBM once per launch of R steps: it is bound by VALU issue, not by HBM.  Its roofline is
+            # the instruction issue rate: SQ_INSTS_VALU per launch (PMC, profiles/pmc_valu.json) / launch time against
+            # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.
+            n_launch = max(1, -(-args.steps // args.rollout)) * passes
+            launch_us_r = kernel_ms * 1e3 / n_launch
             out["mode"] = "fused_rollout_recorded" if args.record else "fused_rollout"
             out["config"]["steps_per_launch"] = args.rollout
             out["config"]["workload"] = workload + f" -- fused rollout, {args.rollout} steps per launch (NOT the per-step headline)"
-            out["roofline"] = {"bound": "valu", "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                               "kernel": "rollout_kernel<%s, 4, flags=%d>" % (args.env, flags),
-                               "launch_us": kernel_ms * 1e3 / max(1, -(-args.steps // args.rollout)),
-                               "ns_per_lane_step": kernel_ms * 1e6 / args.steps / n}
-        if world == 1 and args.cpu_seconds > 0:
+            key = args.env + ("_recorded" if args.record else "")
+            rec_v, note = load_pmc("pmc_valu.json", key, sha)
+            roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instr/s", "frac": None,
+                    "traffic": None, "kernel": "rollout_kernel<%s, %d, flags=%d>" % (args.env, 4, flags), "launch_us": launch_us_r,
+                    "ns_per_lane_step": kernel_ms * 1e6 / steps_timed / n, "kernel_source_sha16": sha}
+            if rec_v and rec_v.get("steps_per_launch") == args.rollout and rec_v.get("lanes") == n:
+                per_launch = rec_v["SQ_INSTS_VALU_per_launch"]
+                roof["achieved"] = per_launch / (launch_us_r * 1e-6) / 1e9
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof["valu_instr_per_wave_step"] = per_launch / (n / 256.0) / args.rollout
+                roof["how"] = ("SQ_INSTS_VALU per launch (profiles/pmc_valu.json, same kernel sources) / HIP-event launch time; peak = "
+                               "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (quarter-rate integer multiplies "
+                               "and LDS/branch issue slots make 1.0 unreachable)")
+            elif note:
+                roof["note"] = note
+            out["roofline"] = roof
+        if info.world == 1 and args.cpu_seconds > 0 and hasattr(backend, "cpu_baseline"):
+            out["cpu_baseline"] = backend.cpu_baseline(kind, args.cpu_seconds)
+        elif info.world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
     eng.close()
-    if dist_on:
-        dist.destroy_process_group()
+    coll.close()
+    return out
+
+
+def main(argv=None) -> int:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    gymrs = importlib.import_module("gym-rs_amd")
+    sharded = gymrs.sharded
+    if sharded.needs_spawn(args.gpus, force=os.environ.get("GYMRS_BENCH_FORCE_SPAWN") == "1"):
+        # plain `python bench.py --gpus N`: become the launcher of N ranks, one process per GPU
+        return sharded.spawn_ranks(str(Path(__file__).resolve()), argv, args.gpus)
+    info = sharded.rank_info()
+    if info.world != args.gpus:
+        if info.is_root:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={info.world} ranks", file=sys.stderr)
+        return 2
+    backend = HipBackend(args, info)
+    out = run_rank(args, info, backend)
+    if out is not None:
+        print(json.dumps(out), flush=True)
     return 0
 
 

@@ -40,11 +40,13 @@ from .envs import (
     RenderMode,
 )
 from ._lib import library_path, load_library
+from . import sharded
+from .engine import params_from_json
 
 __all__ = [
     "ActionReward", "RewardRange", "BoxR", "Discrete", "BatchedEngine", "GymrsError", "InvalidActionError",
     "CartPoleParams", "MountainCarParams", "PendulumParams", "CartPoleEnv", "MountainCarEnv", "PendulumEnv",
     "CartPoleObservation", "MountainCarObservation", "PendulumObservation", "RenderMode",
     "AUTO_RESET", "TRACK_STATS", "TIME_LIMIT", "CARTPOLE", "MOUNTAIN_CAR", "PENDULUM",
-    "library_path", "load_library", "shard_range",
+    "library_path", "load_library", "shard_range", "sharded", "params_from_json",
 ]

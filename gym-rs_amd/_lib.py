@@ -9,6 +9,7 @@ import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
+ABI_VERSION = 2  # GYMRS_ABI_VERSION of include/gymrs_amd.h
 _LIB = None
 
 u8p = C.POINTER(C.c_uint8)
@@ -55,6 +56,11 @@ SIGNATURES = {
     "gymrs_fill_actions": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     "gymrs_get_tick": (C.c_int, [C.c_void_p, u64p, u64p]),
     "gymrs_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gymrs_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gymrs_get_params": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "gymrs_env_json": (C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, u64p]),
+    "gymrs_params_from_json": (C.c_int, [C.c_int, C.c_char_p, C.c_void_p, f64p, C.POINTER(C.c_int)]),
+    "gymrs_copy_probe": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, f64p]),
     "gymrs_last_error": (C.c_char_p, []),
     "gymrs_abi_version": (C.c_int, []),
 }
@@ -86,7 +92,7 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError here = the header and the library disagree
         fn.restype = restype
         fn.argtypes = argtypes
-    if lib.gymrs_abi_version() != 1:
+    if lib.gymrs_abi_version() != ABI_VERSION:
         raise RuntimeError("gym-rs_amd: ABI version mismatch between the binding and the library")
     _LIB = lib
     return lib

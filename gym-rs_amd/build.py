@@ -21,9 +21,11 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 ORACLE = ROOT / "oracle"
 
-HIP_SOURCES = [CSRC / "gymrs_kernels.hip", CSRC / "gymrs_rollout.hip", CSRC / "gymrs_engine.hip"]
+HIP_SOURCES = [CSRC / "gymrs_step_cartpole.hip", CSRC / "gymrs_step_mountain_car.hip", CSRC / "gymrs_step_pendulum.hip",
+               CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip"]
 HIP_HEADERS = [
     CSRC / "gymrs_kernels.h",
+    CSRC / "gymrs_step_impl.h",
     CSRC / "gymrs_tile.h",
     CSRC / "gymrs_physics.h",
     CSRC / "gymrs_philox.h",

@@ -1,0 +1,299 @@
+// gymrs_aux.hip -- the kernels OFF the per-step path: Env::reset for every lane, the synthetic random-policy action
+// stream, the statistics read-out, and two one-thread helpers.  Kept in their own translation unit so that the
+// step-kernel table (gymrs_kernels.hip, minutes of compile time) is not rebuilt when one of these changes.
+#include "gymrs_tile.h"
+
+namespace gymrs {
+
+// ---------------------------------------------------------------------------------------------
+// Env::reset for every lane (cartpole.rs:485-516, mountain_car.rs:464-501): off the per-step path.
+template <class Env>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
+{
+    const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (lane >= a.n) return;
+    const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
+    float ns[Env::kState];
+    Env::sample(r, a.box, ns);
+#pragma unroll
+    for (int j = 0; j < Env::kState; ++j) a.s[j][lane] = ns[j];
+    if (Env::kHasObsExtra) {
+        float sn, cs;
+        sincosf_(ns[0], &sn, &cs);
+        a.obs_cos[lane] = cs;
+        a.obs_sin[lane] = sn;
+    }
+    a.reward[lane] = 0.0f;
+    a.done[lane] = 0;
+    a.truncated[lane] = 0;
+    if (Env::kHasBeyond) a.beyond[lane] = 0; // steps_beyond_terminated = None, cartpole.rs:504
+    a.ep_start[lane] = (uint32_t)(a.tick + 1); // = the epoch the statistics are measured from
+}
+
+// Random-policy actions (examples/cartpole.rs:19 `rng.gen_range(0..=1)`), Philox stream 1.  A work-item serves one
+// aligned group of four global env ids: they share one Philox block (gymrs_philox.h).
+template <class Env>
+__global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Action* out, uint64_t n, uint64_t gid0,
+                                                              uint64_t seed, uint64_t t, uint32_t n_actions,
+                                                              float max_torque)
+{
+    constexpr bool kDiscrete = sizeof(typename Env::Action) == 1;
+    const uint64_t group = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t first_gid = (gid0 & ~3ull) + 4 * group;
+    if (first_gid >= gid0 + n) return;
+    const u32x4 blk = action_block(seed, first_gid, kDiscrete ? (t >> 1) : t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t gid = first_gid + j;
+        if (gid < gid0 || gid >= gid0 + n) continue; // the shard need not start or end on a multiple of 4
+        if constexpr (kDiscrete)
+            out[gid - gid0] = discrete_from_word(blk.v[j], t, n_actions);
+        else
+            out[gid - gid0] = uniform_between(blk.v[j], -max_torque, max_torque);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Statistics read-out (off the hot path; one call per gymrs_stats / gymrs_stats_clear / all-reduce).
+//   L = sum over lanes of (ep_start - epoch) = total length of the episodes finished since the last reset()
+//       (episodes tile a lane's time axis, so the start tick of the open episode is all a lane has to keep),
+//   E = finished episodes, R = sum of returns (Pendulum only; for the constant-reward envs return = +-length).
+// Two launches, no atomics, no memset: stats_partial_kernel streams ep_start (one dwordx4 per work-item per pass,
+// non-temporal) and the per-wavefront slots, reduces inside the wavefront with shuffles, across the 16 wavefronts of
+// a workgroup through 384 bytes of LDS, and writes ONE {L, E, R} triple per workgroup; stats_finalize_kernel (one
+// workgroup) folds the <= 256 triples in a fixed order -- so R, a double, is reproducible from call to call -- and
+// applies the read / clear / after-reset logic.  2^20 lanes: 256 workgroups x 1024 work-items, one pass.
+// (Round 1 used <= 1024 workgroups, three LDS tree reductions and three same-address atomics per workgroup: 40 us.)
+constexpr int kStatsThreads = 1024;
+constexpr int kStatsMaxBlocks = kStatsPartials;
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Workgroup-wide {len, ep, ret} -> valid in work-item 0.  WAVES = wavefronts per workgroup (<= 64).
+template <int WAVES>
+__device__ __forceinline__ void block_sum3(unsigned long long& len, unsigned long long& ep, double& ret)
+{
+    __shared__ unsigned long long s_len[WAVES], s_ep[WAVES];
+    __shared__ double s_ret[WAVES];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    len = wave_sum_u64(len);
+    ep = wave_sum_u64(ep);
+    ret = wave_sum_f64(ret);
+    if (lane == 0) {
+        s_len[wave] = len;
+        s_ep[wave] = ep;
+        s_ret[wave] = ret;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        len = lane < WAVES ? s_len[lane] : 0ull;
+        ep = lane < WAVES ? s_ep[lane] : 0ull;
+        ret = lane < WAVES ? s_ret[lane] : 0.0;
+        len = wave_sum_u64(len);
+        ep = wave_sum_u64(ep);
+        ret = wave_sum_f64(ret);
+    }
+}
+
+__global__ __launch_bounds__(kStatsThreads) void stats_partial_kernel(const uint32_t* __restrict__ ep_start, uint64_t n, uint32_t epoch,
+                                                                      const unsigned long long* __restrict__ bs, uint32_t n_slots,
+                                                                      unsigned long long* __restrict__ partials)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    unsigned long long len = 0, ep = 0;
+    double ret = 0.0;
+    const uint64_t tid = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kStatsThreads;
+    const uint64_t n4 = n >> 2; // ep_start is 256-byte aligned (engine_create)
+    const u4* v = reinterpret_cast<const u4*>(ep_start);
+    for (uint64_t i = tid; i < n4; i += stride) {
+        const u4 x = __builtin_nontemporal_load(v + i);
+        // each difference is taken in 32 bits (ticks wrap), the sum in 64
+        len += (unsigned long long)(uint32_t)(x.x - epoch) + (uint32_t)(x.y - epoch) + (uint32_t)(x.z - epoch) + (uint32_t)(x.w - epoch);
+    }
+    for (uint64_t i = (n4 << 2) + tid; i < n; i += stride) len += (uint32_t)(ep_start[i] - epoch);
+    const ull2* slots = reinterpret_cast<const ull2*>(bs);
+    for (uint64_t b = tid; b < n_slots; b += stride) {
+        const ull2 s = __builtin_nontemporal_load(slots + b);
+        ep += s.x;
+        ret += __builtin_bit_cast(double, (unsigned long long)s.y);
+    }
+    block_sum3<kStatsThreads / 64>(len, ep, ret);
+    if (threadIdx.x == 0) {
+        unsigned long long* out = partials + (size_t)blockIdx.x * 3;
+        out[0] = len;
+        out[1] = ep;
+        out[2] = __builtin_bit_cast(unsigned long long, ret);
+    }
+}
+
+// mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps}; mode 1: remember L as the new base
+// (statistics cleared); mode 2: base = 0 (after reset(); n_partials = 0).
+__global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const unsigned long long* __restrict__ partials, uint32_t n_partials,
+                                                                         unsigned long long* base, int mode, int reward_sign, double n_steps,
+                                                                         double* out4)
+{
+    unsigned long long len = 0, ep = 0;
+    double ret = 0.0;
+    if (threadIdx.x < n_partials) {
+        const unsigned long long* p = partials + (size_t)threadIdx.x * 3;
+        len = p[0];
+        ep = p[1];
+        ret = __builtin_bit_cast(double, p[2]);
+    }
+    block_sum3<kStatsMaxBlocks / 64>(len, ep, ret);
+    if (threadIdx.x != 0) return;
+    if (mode == 1) {
+        base[0] = len;
+        return;
+    }
+    if (mode == 2) {
+        base[0] = 0;
+        return;
+    }
+    const double flen = (double)(len - base[0]);
+    out4[0] = reward_sign != 0 ? reward_sign * flen : ret;
+    out4[1] = flen;
+    out4[2] = (double)ep;
+    out4[3] = n_steps;
+}
+
+hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
+{
+    uint32_t grid = 0;
+    if (mode != 2 && a.track) { // without GYMRS_TRACK_STATS ep_start and the slots carry no statistics
+        const uint64_t items = (a.n >> 2) > a.n_blocks ? (a.n >> 2) : a.n_blocks;
+        const uint64_t want = (items + kStatsThreads - 1) / kStatsThreads;
+        grid = (uint32_t)(want < 1 ? 1 : (want > (uint64_t)kStatsMaxBlocks ? (uint64_t)kStatsMaxBlocks : want));
+        hipLaunchKernelGGL(stats_partial_kernel, dim3(grid), dim3(kStatsThreads), 0, stream, a.ep_start, a.n, a.epoch, a.block_stats,
+                           a.n_blocks, a.partials);
+    }
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(kStatsMaxBlocks), 0, stream, a.partials, grid, a.base, mode, a.reward_sign,
+                       a.n_steps, a.out4);
+    return hipGetLastError();
+}
+
+__global__ void fold_open_kernel(double* wave_open, uint32_t n_slots)
+{
+    double sum = 0.0;
+    for (uint32_t i = 0; i < n_slots; ++i) {
+        sum += wave_open[i];
+        wave_open[i] = 0.0;
+    }
+    wave_open[0] = sum;
+}
+
+hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream)
+{
+    hipLaunchKernelGGL(fold_open_kernel, dim3(1), dim3(1), 0, stream, wave_open, n_slots);
+    return hipGetLastError();
+}
+
+__global__ void tick_advance_kernel(unsigned long long* tick_dev, unsigned long long by) { *tick_dev += by; }
+
+hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, stream, tick_dev, by);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t)((a.n + kBlock - 1) / kBlock);
+    switch (kind) {
+    case GYMRS_CARTPOLE: hipLaunchKernelGGL((reset_kernel<CartPoleT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+    case GYMRS_MOUNTAIN_CAR: hipLaunchKernelGGL((reset_kernel<MountainCarT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+    case GYMRS_PENDULUM: hipLaunchKernelGGL((reset_kernel<PendulumT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
+                               float max_torque, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t groups = (n + (gid0 & 3u) + 3) / 4; // aligned groups of four global ids that touch the shard
+    const uint32_t grid = (uint32_t)((groups + kBlock - 1) / kBlock);
+    switch (kind) {
+    case GYMRS_CARTPOLE:
+        hipLaunchKernelGGL((fill_actions_kernel<CartPoleT>), dim3(grid), dim3(kBlock), 0, stream,
+                           static_cast<uint8_t*>(actions), n, gid0, seed, t, 2u, 0.0f);
+        break;
+    case GYMRS_MOUNTAIN_CAR:
+        hipLaunchKernelGGL((fill_actions_kernel<MountainCarT>), dim3(grid), dim3(kBlock), 0, stream,
+                           static_cast<uint8_t*>(actions), n, gid0, seed, t, 3u, 0.0f);
+        break;
+    case GYMRS_PENDULUM:
+        hipLaunchKernelGGL((fill_actions_kernel<PendulumT>), dim3(grid), dim3(kBlock), 0, stream,
+                           static_cast<float*>(actions), n, gid0, seed, t, 0u, max_torque);
+        break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// gymrs_copy_probe (measurement): the plain copy a step launch of the same size is compared with.
+template <bool NT>
+__global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* __restrict__ src, uint64_t n_read16, uint32_t* __restrict__ dst,
+                                                            uint64_t n_write16)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    u4 v = {(uint32_t)i, 1u, 2u, 3u};
+    if (i < n_read16) v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i) : reinterpret_cast<const u4*>(src)[i];
+    if (i < n_write16) {
+        if (NT)
+            __builtin_nontemporal_store(v, reinterpret_cast<u4*>(dst) + i);
+        else
+            reinterpret_cast<u4*>(dst)[i] = v;
+    } else if (v.x == 0xdeadbeefu && v.y == 0x12345678u) { // keeps the load alive when nothing is written for this item
+        dst[0] = v.z;
+    }
+}
+
+hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream)
+{
+    const uint64_t items = n_read16 > n_write16 ? n_read16 : n_write16;
+    if (items == 0) return hipSuccess;
+    const uint64_t grid = (items + kBlock - 1) / kBlock;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (non_temporal)
+        hipLaunchKernelGGL(copy_probe_kernel<true>, dim3((uint32_t)grid), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src), n_read16,
+                           static_cast<uint32_t*>(dst), n_write16);
+    else
+        hipLaunchKernelGGL(copy_probe_kernel<false>, dim3((uint32_t)grid), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src), n_read16,
+                           static_cast<uint32_t*>(dst), n_write16);
+    return hipGetLastError();
+}
+
+// the per-step kernel tables live in one translation unit per env type
+hipError_t launch_step_cartpole(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
+hipError_t launch_step_mountain_car(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
+hipError_t launch_step_pendulum(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
+
+hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
+                       hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    switch (kind) {
+    case GYMRS_CARTPOLE: return launch_step_cartpole(vec, flags, a, consts, stream);
+    case GYMRS_MOUNTAIN_CAR: return launch_step_mountain_car(vec, flags, a, consts, stream);
+    case GYMRS_PENDULUM: return launch_step_pendulum(vec, flags, a, consts, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace gymrs

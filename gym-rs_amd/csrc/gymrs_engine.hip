@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "gymrs_amd.h"
+#include "gymrs_json.h"
 #include "gymrs_kernels.h"
 
 using namespace gymrs;
@@ -60,6 +61,11 @@ struct gymrs_engine {
         MountainCarConsts mc;
         PendulumConsts pd;
     } consts;
+    union { // the pub physics fields as the caller set them (f64 like the reference's O64); consts is derived from them
+        gymrs_cartpole_params cp;
+        gymrs_mountain_car_params mc;
+        gymrs_pendulum_params pd;
+    } params;
     float max_torque = 2.0f;
     float lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};         // current reset box
     float dflt_lo[4] = {0, 0, 0, 0}, dflt_hi[4] = {0, 0, 0, 0}; // default reset box
@@ -88,7 +94,7 @@ struct gymrs_engine {
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
     double* stats_dev = nullptr;
-    unsigned long long* stats_acc = nullptr;  // [3] scratch of the statistics read-out
+    unsigned long long* stats_acc = nullptr;  // [kStatsPartials][3] scratch of the statistics read-out
     unsigned long long* stats_base = nullptr; // [1] length sum at the last gymrs_stats_clear
     uint32_t epoch = 1;                       // ep_start value written by the last reset()
     void* action_staging = nullptr; // for gymrs_step_host
@@ -157,6 +163,9 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.block_stats = e->block_stats;
     a.err = e->err;
     a.n = e->n;
+    // the vector load of a work-item's actions needs vec * sizeof(action) alignment; any other address is read lane by
+    // lane (n_fast = 0 sends every wavefront through the guarded code)
+    a.n_fast = (reinterpret_cast<uintptr_t>(actions) % ((size_t)e->vec * action_size(e->kind)) == 0) ? e->n : 0;
     a.gid0 = e->gid0;
     a.seed = e->seed;
     a.tick = e->tick;
@@ -175,7 +184,7 @@ static StatsArgs stats_args(const gymrs_engine* e)
     a.epoch = e->epoch;
     a.block_stats = e->block_stats;
     a.n_blocks = e->n_stat_blocks;
-    a.acc = e->stats_acc;
+    a.partials = e->stats_acc;
     a.base = e->stats_base;
     a.track = (e->flags & GYMRS_TRACK_STATS) != 0;
     a.reward_sign = e->kind == GYMRS_CARTPOLE ? 1 : (e->kind == GYMRS_MOUNTAIN_CAR ? -1 : 0);
@@ -368,7 +377,8 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     case GYMRS_CARTPOLE: {
         gymrs_cartpole_params d;
         gymrs_default_params(kind, &d);
-        e->consts.cp = make_consts(params ? *static_cast<const gymrs_cartpole_params*>(params) : d);
+        e->params.cp = params ? *static_cast<const gymrs_cartpole_params*>(params) : d;
+        e->consts.cp = make_consts(e->params.cp);
         e->state_dim = 4;
         e->obs_dim = 4;
         for (int j = 0; j < 4; ++j) { // cartpole.rs:353-361
@@ -380,7 +390,8 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     case GYMRS_MOUNTAIN_CAR: {
         gymrs_mountain_car_params d;
         gymrs_default_params(kind, &d);
-        e->consts.mc = make_consts(params ? *static_cast<const gymrs_mountain_car_params*>(params) : d);
+        e->params.mc = params ? *static_cast<const gymrs_mountain_car_params*>(params) : d;
+        e->consts.mc = make_consts(e->params.mc);
         e->state_dim = 2;
         e->obs_dim = 2;
         e->dflt_lo[0] = -0.6f; // mountain_car.rs:176-187
@@ -390,7 +401,8 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     case GYMRS_PENDULUM: {
         gymrs_pendulum_params d;
         gymrs_default_params(kind, &d);
-        const auto& p = params ? *static_cast<const gymrs_pendulum_params*>(params) : d;
+        e->params.pd = params ? *static_cast<const gymrs_pendulum_params*>(params) : d;
+        const auto& p = e->params.pd;
         e->consts.pd = make_consts(p);
         e->max_steps = e->consts.pd.max_steps;
         e->max_torque = (float)p.max_torque;
@@ -465,7 +477,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
-    chk(dev_alloc(&e->stats_acc, 3));
+    chk(dev_alloc(&e->stats_acc, (size_t)kStatsPartials * 3));
     chk(dev_alloc(&e->stats_base, 1));
     chk(dev_alloc(&e->tick_dev, 1));
     if (st != GYMRS_OK) {
@@ -524,8 +536,8 @@ gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream)
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
-    if (lanes_per_thread != 4 && lanes_per_thread != 8 && lanes_per_thread != 16)
-        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4, 8 or 16");
+    if (lanes_per_thread != 4 && lanes_per_thread != 8)
+        return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4 or 8");
     if (memory_hint < 0 || memory_hint > 2) return fail(GYMRS_EINVAL, "gymrs_set_tuning: memory_hint must be 0, 1 or 2");
     e->vec = lanes_per_thread;
     e->nt_mode = memory_hint;
@@ -927,9 +939,11 @@ struct SnapshotHeader {
     float lo[4], hi[4], max_torque;
     uint32_t consts_bytes;
     unsigned char consts[96];
+    unsigned char params[96]; // the f64 pub fields (gymrs_get_params / the serde view)
 };
 static_assert(sizeof(CartPoleConsts) <= 96 && sizeof(MountainCarConsts) <= 96 && sizeof(PendulumConsts) <= 96, "consts blob too small");
-constexpr uint32_t kSnapshotVersion = 2;
+static_assert(sizeof(gymrs_cartpole_params) <= 96 && sizeof(gymrs_mountain_car_params) <= 96 && sizeof(gymrs_pendulum_params) <= 96, "params blob too small");
+constexpr uint32_t kSnapshotVersion = 3;
 
 struct Segment {
     void* dev;
@@ -969,6 +983,7 @@ void drop_graph(gymrs_engine* e)
 void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
 {
     dst->consts = src->consts;
+    dst->params = src->params;
     dst->max_torque = src->max_torque;
     dst->max_steps = src->max_steps;
     std::memcpy(dst->lo, src->lo, sizeof(dst->lo));
@@ -1046,6 +1061,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
     h.max_torque = e->max_torque;
     h.consts_bytes = (uint32_t)consts_size(e->kind);
     std::memcpy(h.consts, consts_ptr(e), h.consts_bytes);
+    std::memcpy(h.params, &e->params, sizeof(e->params));
     char* p = static_cast<char*>(host_buf);
     std::memcpy(p, &h, sizeof(h));
     p += sizeof(h);
@@ -1094,6 +1110,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
     e->clean_shape = 0;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
+    std::memcpy(&e->params, h.params, sizeof(e->params));
     return GYMRS_OK;
 }
 
@@ -1196,6 +1213,263 @@ gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t see
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_fill_actions: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(launch_fill_actions(e->kind, actions_dev, e->n, e->gid0, seed, t, e->max_torque, e->stream));
+    return GYMRS_OK;
+}
+
+// ---- the pub physics fields after construction -------------------------------------------------------------------
+gymrs_status gymrs_set_params(gymrs_engine* e, const void* params)
+{
+    if (!e || !params) return fail(GYMRS_EINVAL, "gymrs_set_params: NULL argument");
+    switch (e->kind) {
+    case GYMRS_CARTPOLE:
+        e->params.cp = *static_cast<const gymrs_cartpole_params*>(params);
+        e->consts.cp = make_consts(e->params.cp);
+        break;
+    case GYMRS_MOUNTAIN_CAR:
+        e->params.mc = *static_cast<const gymrs_mountain_car_params*>(params);
+        e->consts.mc = make_consts(e->params.mc);
+        break;
+    case GYMRS_PENDULUM:
+        e->params.pd = *static_cast<const gymrs_pendulum_params*>(params);
+        e->consts.pd = make_consts(e->params.pd);
+        e->max_steps = e->consts.pd.max_steps;
+        e->max_torque = (float)e->params.pd.max_torque;
+        break;
+    }
+    // Only the launch constants changed: state, steps_beyond_terminated, episode clocks, statistics, seed and tick
+    // carry on, exactly like assigning a pub field of the reference struct between two step() calls.
+    drop_graph(e); // the constants are baked into a captured graph
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_get_params(gymrs_engine* e, void* params_out)
+{
+    if (!e || !params_out) return fail(GYMRS_EINVAL, "gymrs_get_params: NULL argument");
+    switch (e->kind) {
+    case GYMRS_CARTPOLE: *static_cast<gymrs_cartpole_params*>(params_out) = e->params.cp; break;
+    case GYMRS_MOUNTAIN_CAR: *static_cast<gymrs_mountain_car_params*>(params_out) = e->params.mc; break;
+    case GYMRS_PENDULUM: *static_cast<gymrs_pendulum_params*>(params_out) = e->params.pd; break;
+    }
+    return GYMRS_OK;
+}
+
+// ---- #[derive(Serialize)] view -------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_episode_steps)
+{
+    json::Object g;
+    g.str("kind", e->kind == GYMRS_CARTPOLE ? "CartPole" : (e->kind == GYMRS_MOUNTAIN_CAR ? "MountainCar" : "Pendulum"));
+    g.uint("n_envs", e->n).uint("global_env_id", e->gid0 + lane).uint("flags", e->flags).uint("seed", e->seed).uint("tick", e->tick);
+    g.uint("max_episode_steps", max_episode_steps);
+    return g;
+}
+json::Object metadata_json(std::initializer_list<const char*> modes, unsigned fps)
+{
+    std::string arr = "[";
+    for (const char* m : modes) arr += (arr.size() > 1 ? "," : "") + json::quoted(m);
+    arr += "]";
+    json::Object m;
+    m.raw("render_modes", arr).uint("render_fps", fps).null("marker"); // PhantomData serialises as a unit
+    return m;
+}
+} // namespace
+} // extern "C++"
+
+gymrs_status gymrs_env_json(gymrs_engine* e, uint64_t lane, char* buf, uint64_t cap, uint64_t* needed)
+{
+    if (!e || (!buf && cap != 0)) return fail(GYMRS_EINVAL, "gymrs_env_json: NULL argument");
+    if (lane >= e->n) return fail(GYMRS_EINVAL, "gymrs_env_json: lane out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    float st[4] = {0, 0, 0, 0};
+    uint8_t beyond = 0;
+    for (int j = 0; j < e->state_dim; ++j) HIP_TRY(hipMemcpyAsync(&st[j], e->s[j] + lane, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (e->kind == GYMRS_CARTPOLE) HIP_TRY(hipMemcpyAsync(&beyond, e->beyond + lane, 1, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    double low[4], high[4];
+    int dim = 0;
+    json::Object o;
+    switch (e->kind) {
+    case GYMRS_CARTPOLE: { // field order of cartpole.rs:52-87
+        const gymrs_cartpole_params& p = e->params.cp;
+        gymrs_observation_space(e->kind, &p, low, high, &dim);
+        static const char* names[4] = {"x", "x_dot", "theta", "theta_dot"};
+        json::Object lo, hi, state;
+        for (int j = 0; j < 4; ++j) {
+            lo.num(names[j], low[j]);
+            hi.num(names[j], high[j]);
+            state.num(names[j], (double)st[j]);
+        }
+        json::Object space;
+        space.obj("low", lo).obj("high", hi);
+        o.uint("action_space", 2).obj("observation_space", space).str("render_mode", "None").obj("state", state);
+        o.obj("metadata", metadata_json({"Human", "RgbArray"}, 50)); // cartpole.rs:265-270
+        o.num("gravity", p.gravity).num("masscart", p.masscart).num("masspole", p.masspole).num("length", p.length);
+        o.num("force_mag", p.force_mag).num("tau", p.tau).str("kinematics_integrator", p.kinematics_integrator == 0 ? "Euler" : "Other");
+        o.num("theta_threshold_radians", p.theta_threshold_radians).num("x_threshold", p.x_threshold);
+        // Option<usize>: the engine keeps is_some() (the count only feeds a warning in the reference, cartpole.rs:459-463)
+        if (beyond && !(e->flags & GYMRS_AUTO_RESET))
+            o.uint("steps_beyond_terminated", 0);
+        else
+            o.null("steps_beyond_terminated");
+        o.obj("gymrs", engine_extras(e, lane, e->consts.cp.max_steps));
+        break;
+    }
+    case GYMRS_MOUNTAIN_CAR: { // field order of mountain_car.rs:48-80
+        const gymrs_mountain_car_params& p = e->params.mc;
+        gymrs_observation_space(e->kind, &p, low, high, &dim);
+        o.num("min_position", p.min_position).num("max_position", p.max_position).num("max_speed", p.max_speed);
+        o.num("goal_position", p.goal_position).num("goal_velocity", p.goal_velocity).num("force", p.force).num("gravity", p.gravity);
+        json::Object lo, hi, state, space;
+        lo.num("position", low[0]).num("velocity", low[1]);
+        hi.num("position", high[0]).num("velocity", high[1]);
+        state.num("position", (double)st[0]).num("velocity", (double)st[1]);
+        space.obj("low", lo).obj("high", hi);
+        o.str("render_mode", "None").uint("action_space", 3).obj("observation_space", space).obj("state", state);
+        o.obj("metadata", metadata_json({"Human", "RgbArray", "SingleRgbArray", "None"}, 30)); // mountain_car.rs:108-118
+        o.obj("gymrs", engine_extras(e, lane, e->consts.mc.max_steps));
+        break;
+    }
+    case GYMRS_PENDULUM: { // not in the reference: params, state, engine extras
+        const gymrs_pendulum_params& p = e->params.pd;
+        o.num("max_speed", p.max_speed).num("max_torque", p.max_torque).num("dt", p.dt).num("g", p.g).num("m", p.m).num("l", p.l);
+        json::Object state;
+        state.num("theta", (double)st[0]).num("theta_dot", (double)st[1]);
+        o.str("render_mode", "None").obj("state", state);
+        o.obj("gymrs", engine_extras(e, lane, e->consts.pd.max_steps));
+        break;
+    }
+    }
+    const std::string text = o.text();
+    if (needed) *needed = text.size() + 1;
+    if (cap < text.size() + 1) return fail(GYMRS_EINVAL, "gymrs_env_json: buffer too small (see *needed)");
+    std::memcpy(buf, text.c_str(), text.size() + 1);
+    return GYMRS_OK;
+}
+
+gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* text, void* params, double* state, int* state_dim)
+{
+    if (!text || !params) return fail(GYMRS_EINVAL, "gymrs_params_from_json: NULL argument");
+    if (kind != GYMRS_CARTPOLE && kind != GYMRS_MOUNTAIN_CAR && kind != GYMRS_PENDULUM)
+        return fail(GYMRS_EINVAL, "gymrs_params_from_json: unknown env kind");
+    json::Value root;
+    json::Parser parser(text);
+    if (!parser.parse(root) || root.kind != json::Value::ObjectK)
+        return fail(GYMRS_EINVAL, std::string("gymrs_params_from_json: not a JSON object (stopped at offset ") +
+                                      std::to_string(parser.where() - text) + ")");
+    bool bad = false;
+    auto number = [&](const char* key, double& dst) {
+        const json::Value* v = root.get(key);
+        if (!v) return;
+        if (v->kind == json::Value::Number)
+            dst = v->number;
+        else if (v->kind == json::Value::Null)
+            dst = std::numeric_limits<double>::quiet_NaN(); // serde_json prints non-finite floats as null
+        else
+            bad = true;
+    };
+    uint32_t* max_steps = nullptr;
+    switch (kind) {
+    case GYMRS_CARTPOLE: {
+        auto* p = static_cast<gymrs_cartpole_params*>(params);
+        number("gravity", p->gravity);
+        number("masscart", p->masscart);
+        number("masspole", p->masspole);
+        number("length", p->length);
+        number("force_mag", p->force_mag);
+        number("tau", p->tau);
+        number("theta_threshold_radians", p->theta_threshold_radians);
+        number("x_threshold", p->x_threshold);
+        if (const json::Value* v = root.get("kinematics_integrator")) {
+            if (v->kind == json::Value::String && v->string == "Euler")
+                p->kinematics_integrator = 0;
+            else if (v->kind == json::Value::String && v->string == "Other")
+                p->kinematics_integrator = 1;
+            else
+                bad = true;
+        }
+        max_steps = &p->max_episode_steps;
+        break;
+    }
+    case GYMRS_MOUNTAIN_CAR: {
+        auto* p = static_cast<gymrs_mountain_car_params*>(params);
+        number("min_position", p->min_position);
+        number("max_position", p->max_position);
+        number("max_speed", p->max_speed);
+        number("goal_position", p->goal_position);
+        number("goal_velocity", p->goal_velocity);
+        number("force", p->force);
+        number("gravity", p->gravity);
+        max_steps = &p->max_episode_steps;
+        break;
+    }
+    case GYMRS_PENDULUM: {
+        auto* p = static_cast<gymrs_pendulum_params*>(params);
+        number("max_speed", p->max_speed);
+        number("max_torque", p->max_torque);
+        number("dt", p->dt);
+        number("g", p->g);
+        number("m", p->m);
+        number("l", p->l);
+        max_steps = &p->max_episode_steps;
+        break;
+    }
+    }
+    if (const json::Value* g = root.get("gymrs")) {
+        const json::Value* v = g->kind == json::Value::ObjectK ? g->get("max_episode_steps") : nullptr;
+        if (v && v->kind == json::Value::Number && v->number >= 0 && v->number <= 4294967295.0) *max_steps = (uint32_t)v->number;
+    }
+    int dim = 0;
+    if (const json::Value* st = root.get("state")) {
+        if (st->kind != json::Value::ObjectK) bad = true;
+        if (!bad && state)
+            for (const auto& f : st->fields) {
+                if (dim >= 4 || (f.second.kind != json::Value::Number && f.second.kind != json::Value::Null)) {
+                    bad = true;
+                    break;
+                }
+                state[dim++] = f.second.kind == json::Value::Number ? f.second.number : std::numeric_limits<double>::quiet_NaN();
+            }
+    }
+    if (state_dim) *state_dim = dim;
+    if (bad) return fail(GYMRS_EINVAL, "gymrs_params_from_json: a known field has the wrong JSON type");
+    return GYMRS_OK;
+}
+
+// ---- measurement -------------------------------------------------------------------------------------------------------
+gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int non_temporal,
+                              double* us_per_launch)
+{
+    if (!us_per_launch || launches == 0) return fail(GYMRS_EINVAL, "gymrs_copy_probe: NULL output or zero launches");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GYMRS_EHIP, "gymrs_copy_probe: no HIP device available; this library has no CPU fallback");
+    if (device < 0 || device >= n_dev) return fail(GYMRS_EINVAL, "gymrs_copy_probe: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t n_read = read_bytes / 16, n_write = write_bytes / 16;
+    void *src = nullptr, *dst = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t err = hipMalloc(&src, n_read * 16 + 256);
+    if (err == hipSuccess) err = hipMalloc(&dst, n_write * 16 + 256);
+    if (err == hipSuccess) err = hipMemset(src, 0, n_read * 16 + 256);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&ev0);
+    if (err == hipSuccess) err = hipEventCreate(&ev1);
+    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    if (err == hipSuccess) err = hipEventRecord(ev0, stream);
+    for (uint32_t i = 0; i < launches && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+    if (err == hipSuccess) err = hipEventRecord(ev1, stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(stream);
+    float ms = 0.0f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, ev0, ev1);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("gymrs_copy_probe: ") + hipGetErrorString(err));
+    *us_per_launch = (double)ms * 1e3 / (double)launches;
     return GYMRS_OK;
 }
 

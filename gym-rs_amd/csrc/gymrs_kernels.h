@@ -24,8 +24,9 @@ struct StepArgs {
     uint32_t* wave_clean; // [n_waves] constant-reward envs under auto-reset: != 0 = the wave's part of `reward` holds the constant
     double* wave_open;  // [n_waves] Pendulum with GYMRS_TRACK_STATS: per-wavefront sum of the rewards of the open episodes
     unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
-    uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane + 1
+    uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
     uint64_t n;         // lanes in this engine
+    uint64_t n_fast;    // n, or 0 when the action buffer is not aligned for the vector load (step_kernel)
     uint64_t gid0;      // global id of lane 0
     uint64_t seed;
     uint64_t tick;      // engine tick of this launch; when tick_base != NULL it is an OFFSET added to *tick_base
@@ -66,7 +67,7 @@ struct ResetArgs {
     SampleBox box;
 };
 
-// Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4, 8 or 16).
+// Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4 or 8).
 inline uint32_t step_grid(uint64_t n, int vec, int threads = kBlock)
 {
     const uint64_t per_block = (uint64_t)threads * vec;
@@ -83,13 +84,14 @@ hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t str
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);
+constexpr int kStatsPartials = 256; // workgroups of the statistics read-out (= work-items of its finalize step)
 struct StatsArgs {
     const uint32_t* ep_start;
     uint64_t n;
     uint32_t epoch;    // value reset() wrote into ep_start
     const unsigned long long* block_stats;
     uint32_t n_blocks;
-    unsigned long long* acc;  // [3] scratch: L, E, R
+    unsigned long long* partials; // [kStatsPartials][3] scratch: one {L, E, R} triple per workgroup of the read-out
     unsigned long long* base; // [1] L at the last stats_clear
     int track;                // GYMRS_TRACK_STATS set
     int reward_sign;          // +1 CartPole, -1 MountainCar (return = +-length), 0 Pendulum (summed)
@@ -98,5 +100,7 @@ struct StatsArgs {
 };
 // mode 0 read, 1 clear (base = L), 2 after reset (base = 0)
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
+// gymrs_copy_probe: one work-item per 16 bytes; reads n_read16 and writes n_write16 16-byte items
+hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream);
 
 } // namespace gymrs

@@ -1,4 +1,6 @@
-// gymrs_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batched classic-control stepper.
+// gymrs_step_impl.h — the hand-written CDNA4 (gfx950) per-step kernel of the batched classic-control stepper and its
+// launch table.  Included by ONE translation unit per env type (gymrs_step_<env>.hip), which the build compiles in
+// parallel: the table (lanes per work-item x flag sets x workgroup sizes) is minutes of compile time.
 //
 // One kernel template, instantiated per env type: each lane is one independent gym-rs env
 //   CartPoleEnv::step     /root/reference/src/envs/classical_control/cartpole.rs:398-483
@@ -30,6 +32,7 @@
 //     tick its next episode starts at (episodes tile a lane's time axis, so the sum of finished lengths
 //     is sum(ep_start) - n*epoch, evaluated when statistics are read) and every wave keeps a private
 //     episode counter slot (plain load at start, plain store at end; no atomics).
+#pragma once
 #include "gymrs_tile.h"
 
 namespace gymrs {
@@ -91,7 +94,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
 template <class Env, int VEC, uint32_t FLAGS, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
-    float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n, const StepArgs rest,
+    float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs rest,
     const typename Env::Consts c)
 {
     constexpr int LPB = THREADS * VEC;
@@ -102,119 +105,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 /
     a.s[2] = s2;
     a.s[3] = s3;
     a.action = action;
-    a.n = n;
     // wave-uniform: every wavefront whose 64 * VEC lanes all exist runs the unguarded body; only the one that
-    // straddles n (and the empty ones behind it) takes the guarded per-lane code
-    if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= a.n)
+    // straddles n (and the empty ones behind it) takes the guarded per-lane code.  n_fast (a preloaded scalar
+    // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
+    // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
+    if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
         step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Env::reset for every lane (cartpole.rs:485-516, mountain_car.rs:464-501): off the per-step path.
-template <class Env>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
-{
-    const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (lane >= a.n) return;
-    const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
-    float ns[Env::kState];
-    Env::sample(r, a.box, ns);
-#pragma unroll
-    for (int j = 0; j < Env::kState; ++j) a.s[j][lane] = ns[j];
-    if (Env::kHasObsExtra) {
-        float sn, cs;
-        sincosf_(ns[0], &sn, &cs);
-        a.obs_cos[lane] = cs;
-        a.obs_sin[lane] = sn;
-    }
-    a.reward[lane] = 0.0f;
-    a.done[lane] = 0;
-    a.truncated[lane] = 0;
-    if (Env::kHasBeyond) a.beyond[lane] = 0; // steps_beyond_terminated = None, cartpole.rs:504
-    a.ep_start[lane] = (uint32_t)(a.tick + 1); // = the epoch the statistics are measured from
-}
-
-// Random-policy actions (examples/cartpole.rs:19 `rng.gen_range(0..=1)`), Philox stream 1.  A work-item serves one
-// aligned group of four global env ids: they share one Philox block (gymrs_philox.h).
-template <class Env>
-__global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Action* out, uint64_t n, uint64_t gid0,
-                                                              uint64_t seed, uint64_t t, uint32_t n_actions,
-                                                              float max_torque)
-{
-    constexpr bool kDiscrete = sizeof(typename Env::Action) == 1;
-    const uint64_t group = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    const uint64_t first_gid = (gid0 & ~3ull) + 4 * group;
-    if (first_gid >= gid0 + n) return;
-    const u32x4 blk = action_block(seed, first_gid, kDiscrete ? (t >> 1) : t);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t gid = first_gid + j;
-        if (gid < gid0 || gid >= gid0 + n) continue; // the shard need not start or end on a multiple of 4
-        if constexpr (kDiscrete)
-            out[gid - gid0] = discrete_from_word(blk.v[j], t, n_actions);
-        else
-            out[gid - gid0] = uniform_between(blk.v[j], -max_torque, max_torque);
-    }
-}
-
-// Statistics read-out (off the hot path).  acc = {L, E, R}: L = sum over lanes of
-// (ep_start - epoch) = total length of the episodes finished since the last reset() (episodes tile a
-// lane's time axis), E = finished episodes, R = sum of returns (Pendulum only; for the const-reward
-// envs return = +-length).
-__global__ __launch_bounds__(kBlock) void stats_accumulate_kernel(const uint32_t* __restrict__ ep_start, uint64_t n,
-                                                                  uint32_t epoch,
-                                                                  const unsigned long long* __restrict__ bs,
-                                                                  uint32_t n_slots, unsigned long long* __restrict__ acc)
-{
-    __shared__ unsigned long long s_len[kBlock], s_ep[kBlock];
-    __shared__ double s_ret[kBlock];
-    unsigned long long len = 0, ep = 0;
-    double ret = 0.0;
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) len += (uint32_t)(ep_start[i] - epoch);
-    for (uint64_t b = (uint64_t)blockIdx.x * kBlock + threadIdx.x; b < n_slots; b += stride) {
-        ep += bs[b * 2];
-        ret += reinterpret_cast<const double*>(bs)[b * 2 + 1];
-    }
-    s_len[threadIdx.x] = len;
-    s_ep[threadIdx.x] = ep;
-    s_ret[threadIdx.x] = ret;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-            s_len[threadIdx.x] += s_len[threadIdx.x + off];
-            s_ep[threadIdx.x] += s_ep[threadIdx.x + off];
-            s_ret[threadIdx.x] += s_ret[threadIdx.x + off];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd(acc + 0, s_len[0]);
-        atomicAdd(acc + 1, s_ep[0]);
-        atomicAdd(reinterpret_cast<double*>(acc + 2), s_ret[0]);
-    }
-}
-
-// mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps}; mode 1: remember L as the new base
-// (statistics cleared); mode 2: base = 0 (after reset()).
-__global__ void stats_finalize_kernel(const unsigned long long* acc, unsigned long long* base, int mode, int reward_sign,
-                                      double n_steps, double* out4)
-{
-    if (mode == 1) {
-        base[0] = acc[0];
-        return;
-    }
-    if (mode == 2) {
-        base[0] = 0;
-        return;
-    }
-    const double len = (double)(acc[0] - base[0]);
-    out4[0] = reward_sign != 0 ? reward_sign * len : *reinterpret_cast<const double*>(acc + 2);
-    out4[1] = len;
-    out4[2] = (double)acc[1];
-    out4[3] = n_steps;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,12 +123,12 @@ static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t 
     if constexpr (Env::kThreads != kBlock) {
         if (a.n >= (uint64_t)Env::kThreads * VEC * 512) { // >= 2 big workgroups per CU
             hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
-                               stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
+                               stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
-                       a.s[2], a.s[3], a.action, a.n, a, *static_cast<const typename Env::Consts*>(consts));
+                       a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }
 
@@ -263,97 +161,8 @@ static hipError_t launch_vec(int vec, uint32_t flags, const StepArgs& a, const v
     switch (vec) {
     case 4: return launch_flags<Env, 4>(flags, a, consts, stream);
     case 8: return launch_flags<Env, 8>(flags, a, consts, stream);
-    case 16: return launch_flags<Env, 16>(flags, a, consts, stream);
     default: return hipErrorInvalidValue;
     }
-}
-
-hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
-                       hipStream_t stream)
-{
-    if (a.n == 0) return hipSuccess;
-    switch (kind) {
-    case GYMRS_CARTPOLE: return launch_vec<CartPoleT>(vec, flags, a, consts, stream);
-    case GYMRS_MOUNTAIN_CAR: return launch_vec<MountainCarT>(vec, flags, a, consts, stream);
-    case GYMRS_PENDULUM: return launch_vec<PendulumT>(vec, flags, a, consts, stream);
-    default: return hipErrorInvalidValue;
-    }
-}
-
-__global__ void fold_open_kernel(double* wave_open, uint32_t n_slots)
-{
-    double sum = 0.0;
-    for (uint32_t i = 0; i < n_slots; ++i) {
-        sum += wave_open[i];
-        wave_open[i] = 0.0;
-    }
-    wave_open[0] = sum;
-}
-
-hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream)
-{
-    hipLaunchKernelGGL(fold_open_kernel, dim3(1), dim3(1), 0, stream, wave_open, n_slots);
-    return hipGetLastError();
-}
-
-__global__ void tick_advance_kernel(unsigned long long* tick_dev, unsigned long long by) { *tick_dev += by; }
-
-hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream)
-{
-    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, stream, tick_dev, by);
-    return hipGetLastError();
-}
-
-hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream)
-{
-    if (a.n == 0) return hipSuccess;
-    const uint32_t grid = (uint32_t)((a.n + kBlock - 1) / kBlock);
-    switch (kind) {
-    case GYMRS_CARTPOLE: hipLaunchKernelGGL((reset_kernel<CartPoleT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
-    case GYMRS_MOUNTAIN_CAR: hipLaunchKernelGGL((reset_kernel<MountainCarT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
-    case GYMRS_PENDULUM: hipLaunchKernelGGL((reset_kernel<PendulumT>), dim3(grid), dim3(kBlock), 0, stream, a); break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
-                               float max_torque, hipStream_t stream)
-{
-    if (n == 0) return hipSuccess;
-    const uint64_t groups = (n + (gid0 & 3u) + 3) / 4; // aligned groups of four global ids that touch the shard
-    const uint32_t grid = (uint32_t)((groups + kBlock - 1) / kBlock);
-    switch (kind) {
-    case GYMRS_CARTPOLE:
-        hipLaunchKernelGGL((fill_actions_kernel<CartPoleT>), dim3(grid), dim3(kBlock), 0, stream,
-                           static_cast<uint8_t*>(actions), n, gid0, seed, t, 2u, 0.0f);
-        break;
-    case GYMRS_MOUNTAIN_CAR:
-        hipLaunchKernelGGL((fill_actions_kernel<MountainCarT>), dim3(grid), dim3(kBlock), 0, stream,
-                           static_cast<uint8_t*>(actions), n, gid0, seed, t, 3u, 0.0f);
-        break;
-    case GYMRS_PENDULUM:
-        hipLaunchKernelGGL((fill_actions_kernel<PendulumT>), dim3(grid), dim3(kBlock), 0, stream,
-                           static_cast<float*>(actions), n, gid0, seed, t, 0u, max_torque);
-        break;
-    default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
-{
-    hipError_t err = hipMemsetAsync(a.acc, 0, 3 * sizeof(unsigned long long), stream);
-    if (err != hipSuccess) return err;
-    if (mode != 2) {
-        const uint64_t work = a.track ? a.n : 0; // without GYMRS_TRACK_STATS ep_start carries no statistics
-        uint32_t grid = (uint32_t)((work + kBlock - 1) / kBlock);
-        grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
-        hipLaunchKernelGGL(stats_accumulate_kernel, dim3(grid), dim3(kBlock), 0, stream, a.ep_start, work, a.epoch,
-                           a.block_stats, a.track ? a.n_blocks : 0u, a.acc);
-    }
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(1), 0, stream, a.acc, a.base, mode, a.reward_sign, a.n_steps, a.out4);
-    return hipGetLastError();
 }
 
 } // namespace gymrs

@@ -78,6 +78,17 @@ def default_params(kind: int):
     return p
 
 
+def params_from_json(kind: int, text: str, params=None):
+    """Inverse of ``BatchedEngine.env_json`` for the physics fields: (params, state or None).  Missing keys keep the
+    value in ``params`` (default: the env's defaults)."""
+    lib = load_library()
+    p = params if params is not None else default_params(kind)
+    state = (C.c_double * 4)()
+    dim = C.c_int()
+    _check(lib, lib.gymrs_params_from_json(int(kind), text.encode("utf-8"), C.byref(p), state, C.byref(dim)))
+    return p, ([state[j] for j in range(dim.value)] if dim.value else None)
+
+
 def _check(lib, status: int) -> None:
     if status == _OK:
         return
@@ -173,8 +184,33 @@ class BatchedEngine:
         _check(self._lib, self._lib.gymrs_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_tuning(self, lanes_per_thread: int = 4, memory_hint: int = 0) -> None:
-        """memory_hint: 0 automatic, 1 always non-temporal accesses, 2 never."""
+        """lanes_per_thread: 4 or 8.  memory_hint: 0 automatic, 1 always non-temporal accesses, 2 never."""
         _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), int(memory_hint)))
+
+    # -- the pub physics fields after construction; the Serialize view -------------------------------
+    def set_params(self, params) -> None:
+        """Assign the pub physics fields (cartpole.rs:53-82) of every lane: only the launch constants change --
+        state, steps_beyond_terminated, episode clocks, statistics, seed and tick carry on."""
+        if not isinstance(params, _PARAMS[self.kind]):
+            raise TypeError(f"expected {_PARAMS[self.kind].__name__}")
+        _check(self._lib, self._lib.gymrs_set_params(self._h, C.byref(params)))
+        self.params = type(params).from_buffer_copy(params)
+
+    def get_params(self):
+        p = _PARAMS[self.kind]()
+        _check(self._lib, self._lib.gymrs_get_params(self._h, C.byref(p)))
+        return p
+
+    def env_json(self, lane: int = 0) -> str:
+        """What ``serde_json::to_string(&env)`` prints for the reference env lane ``lane`` stands for (core.rs:25)."""
+        need = C.c_uint64()
+        buf = C.create_string_buffer(2048)
+        st = self._lib.gymrs_env_json(self._h, int(lane), buf, len(buf), C.byref(need))
+        if st != _OK and need.value > len(buf):
+            buf = C.create_string_buffer(need.value)
+            st = self._lib.gymrs_env_json(self._h, int(lane), buf, len(buf), C.byref(need))
+        _check(self._lib, st)
+        return buf.value.decode("utf-8")
 
     # -- Env::reset ------------------------------------------------------------------------------
     def reset(self, seed: Optional[int] = None, options: Optional[Sequence[float]] = None) -> int:

@@ -101,13 +101,17 @@ class _SingleEnv:
 
     def __setattr__(self, name, value):
         if name in type(self)._FIELDS:
+            # Assigning a pub field of the reference struct touches nothing else (cartpole.rs:455-464 reads the fields
+            # afresh on every step): gymrs_set_params swaps only the launch constants -- the engine, its device, the
+            # state, steps_beyond_terminated, seed/tick and the last reward/done all carry on.
             setattr(self._params, name, value)
-            state = self._engine.get_state()
-            self._engine.close()
-            object.__setattr__(self, "_engine", BatchedEngine(self._KIND, 1, params=self._params, flags=0))
-            self._engine.set_state(state)
+            self._engine.set_params(self._params)
         else:
             object.__setattr__(self, name, value)
+
+    def to_json(self) -> str:
+        """``serde_json::to_string(&env)``: the serde-visible fields under the reference's names (core.rs:25)."""
+        return self._engine.env_json(0)
 
     def _options(self, options: Optional[BoxR]):
         if options is None:
@@ -249,6 +253,15 @@ class PendulumEnv(_SingleEnv):
         reward, done, _ = self._engine.get_step_result()
         return ActionReward(self._obs(), float(reward[0]), bool(done[0]), False, None)
 
+    def _options(self, options):
+        """``options``: a BoxR over the (theta, theta_dot) state -- a pair of 2-sequences -- or a flat
+        [theta_low, theta_dot_low, theta_high, theta_dot_high] list."""
+        if options is None:
+            return None
+        if isinstance(options, BoxR):
+            return [float(v) for v in options.low] + [float(v) for v in options.high]
+        return [float(v) for v in options]
+
     def reset(self, seed: Optional[int] = None, return_info: bool = False, options=None):
-        self._engine.reset(seed, options)
+        self._engine.reset(seed, self._options(options))
         return self._obs(), (() if return_info else None)

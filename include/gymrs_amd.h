@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GYMRS_ABI_VERSION 1
+#define GYMRS_ABI_VERSION 2
 
 typedef struct gymrs_engine gymrs_engine; /* opaque; owns device buffers + stream */
 
@@ -41,8 +41,13 @@ typedef enum {
     GYMRS_ENCCL = 3,   /* RCCL error */
     GYMRS_ENOMEM = 4,  /* allocation failed */
     GYMRS_EACTION = 5, /* an action outside the action space was seen (reference: assert! panic,
-                          cartpole.rs:402-406, mountain_car.rs:402-406); the offending lanes were
-                          left untouched */
+                          cartpole.rs:402-406, mountain_car.rs:402-406).  The offending lanes' STATE is
+                          left untouched (the reference panics before touching the env); their reward /
+                          done / truncated entries of that step read 0.  The engine tick still advances
+                          for every lane, so with GYMRS_TIME_LIMIT / GYMRS_TRACK_STATS the episode clock
+                          and the statistics of a lane whose action was rejected count the rejected
+                          step: treat statistics as undefined once GYMRS_EACTION has been reported
+                          (the reference would have aborted the process). */
 } gymrs_status;
 
 /* classical_control/mod.rs:1-4 exports cartpole and mountain_car.  Pendulum is NOT in the
@@ -136,7 +141,11 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
 
 /* ---- Env::step(action) (core.rs:42) --------------------------------------------------------- */
 /* actions_dev: n_envs actions on the device: uint8_t for CartPole {0,1} / MountainCar {0,1,2},
- * float for Pendulum.  Asynchronous.  Results land in the arrays below. */
+ * float for Pendulum.  Asynchronous.  Results land in the arrays below.
+ * Alignment: a buffer aligned to lanes_per_thread * sizeof(action) bytes (4 or 8 B for u8 actions, 16 or 32 B
+ * for f32; any hipMalloc / torch allocation is) is read with one vector load per work-item.  Any other address
+ * is accepted too and read lane by lane (every wavefront then takes the guarded per-lane code: correct, slower).
+ * The same holds for every ring slot actions_dev + k * stride_bytes of gymrs_step_many. */
 gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev);
 /* Same with a host action buffer (copied first); for the single-env compatibility layer. */
 gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host);
@@ -223,6 +232,47 @@ gymrs_status gymrs_comm_unique_id(uint8_t id_out[128]);
 gymrs_status gymrs_comm_init(gymrs_engine* e, int n_ranks, int rank, const uint8_t id[128]);
 gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
 
+/* ---- the `pub` physics fields after construction (cartpole.rs:53-82, mountain_car.rs:49-62) --- */
+/* In the reference the constants are public struct fields: `env.gravity = ...` between two step() calls touches
+ * nothing else -- state, steps_beyond_terminated, the episode clock and the PRNG carry on (cartpole.rs:455-464 reads
+ * the fields afresh on every step).  gymrs_set_params is that assignment for every lane of the engine: only the
+ * constants change (the next launch uses them; a captured HIP graph is dropped); no device array, no tick, no
+ * statistics are touched.  params = the env kind's params struct (not NULL).  gymrs_get_params reads them back
+ * in f64 exactly as they were set (the f32 conversion happens per launch-constant block, not in this copy). */
+gymrs_status gymrs_set_params(gymrs_engine* e, const void* params);
+gymrs_status gymrs_get_params(gymrs_engine* e, void* params_out);
+
+/* ---- `#[derive(Serialize)]` view (core.rs:25; cartpole.rs:51-87, mountain_car.rs:46-80) -------- */
+/* What serde_json::to_string(&env) prints for the reference env that lane `lane` stands for: the serde-visible
+ * fields in declaration order with the reference's field names -- CartPole: action_space, observation_space
+ * {low, high}, render_mode, state {x, x_dot, theta, theta_dot}, metadata {render_modes, render_fps, marker},
+ * gravity, masscart, masspole, length, force_mag, tau, kinematics_integrator ("Euler" | "Other"),
+ * theta_threshold_radians, x_threshold, steps_beyond_terminated (null | 0; the reference counts further, the engine
+ * keeps is_some()); MountainCar: min_position .. gravity, render_mode, action_space, observation_space, state
+ * {position, velocity}, metadata.  Non-finite floats print as null (serde_json).  `rand_random` is
+ * #[serde(skip_serializing)] in the reference and absent here; the GUI-only `renderer` / `screen` members are
+ * omitted (RenderMode::None, out of scope).  Engine-side additions sit under one extra key "gymrs": {kind, n_envs,
+ * global_env_id, flags, seed, tick, max_episode_steps}.  Pendulum (not in the reference) prints its params, state
+ * and the "gymrs" object.
+ * Writes at most cap bytes incl. the terminating NUL; *needed (may be NULL) receives the size required.  Returns
+ * GYMRS_EINVAL when cap is too small (nothing useful written).  Synchronising (reads the lane's state). */
+gymrs_status gymrs_env_json(gymrs_engine* e, uint64_t lane, char* buf, uint64_t cap, uint64_t* needed);
+/* The inverse for the physics fields: parse a JSON object as printed above (unknown keys ignored, missing keys keep
+ * the value already in *params, which the caller initialises, e.g. with gymrs_default_params) into the kind's
+ * params struct.  If `state` (may be NULL, capacity 4) is given and the object has a "state", its numbers are stored
+ * in field order and *state_dim (may be NULL) is set (0 when absent). */
+gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* json, void* params, double* state, int* state_dim);
+
+/* ---- measurement ("also measure an in-repo stream-copy kernel on the box") ---------- */
+/* Times `launches` back-to-back launches of a plain dwordx4 copy kernel that reads read_bytes and writes write_bytes
+ * per launch (private buffers on `device`, one work-item per 16 bytes, HIP events on a private stream, 3 warm-up
+ * launches) and returns the mean microseconds per launch.  With read/write sizes of one step's traffic this is the
+ * floor a step launch of that size can reach on this box (it includes the fixed cost of a dependent launch); with
+ * sizes beyond the 256 MiB Infinity Cache it is the HBM bandwidth a kernel can actually get.  non_temporal != 0
+ * uses nt loads/stores like the step kernel does below 48 MiB per step. */
+gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int non_temporal,
+                              double* us_per_launch);
+
 /* ---- utilities --------------------------------------------------------------------------------- */
 /* Random-policy actions for lane block [0, n_envs) at time t, written to actions_dev: the
  * `rng.gen_range(0..=1)` of examples/cartpole.rs:19, generated on the device so no PCIe traffic
@@ -230,8 +280,8 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
 gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t seed, uint64_t t);
 /* Engine tick (number of reset()/step() calls since the last seeded reset) and current seed. */
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
-/* Kernel tuning knobs for benchmarks; results never depend on them.  lanes_per_thread: 4 (default), 8 or
- * 16 lanes per work-item.  memory_hint: 0 = automatic (non-temporal loads/stores while one step's traffic is
+/* Kernel tuning knobs for benchmarks; results never depend on them.  lanes_per_thread: 4 (default) or 8
+ * lanes per work-item (16 was measured 4x slower everywhere and was removed in ABI 2).  memory_hint: 0 = automatic (non-temporal loads/stores while one step's traffic is
  * <= 48 MiB), 1 = always non-temporal, 2 = never. */
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint);
 

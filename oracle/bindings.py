@@ -202,6 +202,8 @@ class Twin:
         L.twin_create.restype = C.c_void_p
         L.twin_create.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32]
         L.twin_destroy.argtypes = [C.c_void_p]
+        L.twin_set_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.twin_set_params.restype = None
         L.twin_reset.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.twin_step.argtypes = [C.c_void_p, C.c_void_p]
         L.twin_get_state.argtypes = [C.c_void_p, C.c_void_p]
@@ -253,6 +255,9 @@ class TwinEngine:
         if getattr(self, "h", None):
             self.lib.twin_destroy(self.h)
             self.h = None
+
+    def set_params(self, params):
+        self.lib.twin_set_params(self.h, C.byref(params))
 
     def reset(self, seed: int, bounds=None):
         arr = None if bounds is None else np.ascontiguousarray(bounds, np.float32)

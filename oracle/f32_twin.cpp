@@ -90,6 +90,20 @@ twin_engine* twin_create(int kind, uint64_t n, uint64_t gid0, const void* params
 
 void twin_destroy(twin_engine* e) { delete e; }
 
+// gymrs_set_params: assigning the pub physics fields between two steps changes the constants and nothing else
+void twin_set_params(twin_engine* e, const void* params)
+{
+    if (e->kind == GYMRS_CARTPOLE) {
+        e->cp = make_consts(*static_cast<const gymrs_cartpole_params*>(params));
+    } else if (e->kind == GYMRS_MOUNTAIN_CAR) {
+        e->mc = make_consts(*static_cast<const gymrs_mountain_car_params*>(params));
+    } else {
+        const auto& p = *static_cast<const gymrs_pendulum_params*>(params);
+        e->pd = make_consts(p);
+        e->max_torque = (float)p.max_torque;
+    }
+}
+
 static int state_dim(const twin_engine* e) { return e->kind == GYMRS_CARTPOLE ? 4 : 2; }
 
 static void sample_lane(twin_engine* e, uint64_t i, uint64_t tick)

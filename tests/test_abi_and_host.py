@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol(gymrs):
 
     sigs = import_module("gym-rs_amd._lib").SIGNATURES
     assert sorted(sigs) == names, "ctypes binding table and header disagree"
-    assert lib.gymrs_abi_version() == 1
+    assert lib.gymrs_abi_version() == 2
 
 
 def test_default_params_match_reference_constants(gymrs, golden):

@@ -135,9 +135,10 @@ def test_pendulum_returns_survive_a_change_of_launch_shape(gymrs, twin):
             t += 1
 
     eager(7)
-    eng.set_tuning(16)
+    eng.set_tuning(8)
     eager(11)
-    fused(9)          # rollout runs 4 lanes per work-item
+    eng.set_tuning(4)
+    fused(9)          # the launch shape changes in mid-episode: the open sums are gathered first
     eng.set_tuning(8)
     eager(13)         # crosses the 30-step limit: every lane's episode closes here
     fused(25)
