@@ -58,11 +58,14 @@ __global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Acti
 //   L = sum over lanes of (ep_start - epoch) = total length of the episodes finished since the last reset()
 //       (episodes tile a lane's time axis, so the start tick of the open episode is all a lane has to keep),
 //   E = finished episodes, R = sum of returns (Pendulum only; for the constant-reward envs return = +-length).
-// Two launches, no atomics, no memset: stats_partial_kernel streams ep_start (one dwordx4 per work-item per pass,
-// non-temporal) and the per-wavefront slots, reduces inside the wavefront with shuffles, across the 16 wavefronts of
-// a workgroup through 384 bytes of LDS, and writes ONE {L, E, R} triple per workgroup; stats_finalize_kernel (one
-// workgroup) folds the <= 256 triples in a fixed order -- so R, a double, is reproducible from call to call -- and
-// applies the read / clear / after-reset logic.  2^20 lanes: 256 workgroups x 1024 work-items, one pass.
+// Two launches, no atomics, no memset: stats_partial_kernel streams ep_start (one dwordx4 per work-item per pass) and
+// the per-wavefront slots, reduces inside the wavefront with shuffles, across the 16 wavefronts of a workgroup
+// through 384 bytes of LDS, and writes ONE {L, E, R} triple per workgroup; stats_finalize_kernel (one workgroup)
+// folds the <= 256 triples in a fixed order -- so R, a double, is reproducible from call to call -- and applies the
+// read / clear / after-reset logic.  2^20 lanes: 256 workgroups x 1024 work-items, one pass.
+// The loads are PLAIN on purpose.  Measured: a non-temporal sweep leaves ep_start outside the Infinity Cache, and
+// every following step launch then pays 0.36 us more (6.79 -> 7.15 us at 2^20 CartPole lanes) for its ~47k scattered
+// 4-byte ep_start stores until something brings the array back.
 // (Round 1 used <= 1024 workgroups, three LDS tree reductions and three same-address atomics per workgroup: 40 us.)
 constexpr int kStatsThreads = 1024;
 constexpr int kStatsMaxBlocks = kStatsPartials;
@@ -118,14 +121,14 @@ __global__ __launch_bounds__(kStatsThreads) void stats_partial_kernel(const uint
     const uint64_t n4 = n >> 2; // ep_start is 256-byte aligned (engine_create)
     const u4* v = reinterpret_cast<const u4*>(ep_start);
     for (uint64_t i = tid; i < n4; i += stride) {
-        const u4 x = __builtin_nontemporal_load(v + i);
+        const u4 x = v[i]; // plain, not non-temporal: see above
         // each difference is taken in 32 bits (ticks wrap), the sum in 64
         len += (unsigned long long)(uint32_t)(x.x - epoch) + (uint32_t)(x.y - epoch) + (uint32_t)(x.z - epoch) + (uint32_t)(x.w - epoch);
     }
     for (uint64_t i = (n4 << 2) + tid; i < n; i += stride) len += (uint32_t)(ep_start[i] - epoch);
     const ull2* slots = reinterpret_cast<const ull2*>(bs);
     for (uint64_t b = tid; b < n_slots; b += stride) {
-        const ull2 s = __builtin_nontemporal_load(slots + b);
+        const ull2 s = slots[b];
         ep += s.x;
         ret += __builtin_bit_cast(double, (unsigned long long)s.y);
     }
@@ -242,6 +245,60 @@ hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, u
         break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reset-log fold on demand (off the hot path; the per-step kernel folds a FULL ring itself, see step_block).  The
+// per-step kernel of a constant-reward env with statistics and no time limit records a step's re-armed lanes as
+// done-masks: row (tick % kResetLogRows) of the ring, word (wave * VEC + k), bit = work-item of the wave, i.e.
+// lane = wave * 64 * VEC + bit * VEC + k.  One work-item folds one word column: it walks the pending rows from the
+// newest to the oldest, gives every lane whose bit it sees for the FIRST time its episode start (the tick after that
+// row's step: episodes tile a lane's time axis, so only the most recent re-arm matters), counts all bits (= finished
+// episodes) and zeroes what it read.  Runs before anything that reads ep_start or the counters (statistics, snapshot,
+// clone, the rollout kernel) and when the launch shape changes.
+constexpr int kFoldThreads = 64;
+
+__global__ __launch_bounds__(kFoldThreads) void fold_reset_log_kernel(unsigned long long* __restrict__ log, uint32_t row_words,
+                                                                      uint64_t first_tick, uint32_t pending, int vec,
+                                                                      uint32_t* __restrict__ ep_start, uint64_t n,
+                                                                      unsigned long long* __restrict__ block_stats)
+{
+    const uint32_t word = blockIdx.x * kFoldThreads + threadIdx.x;
+    if (word >= row_words) return;
+    const uint64_t lane0 = (uint64_t)(word / (uint32_t)vec) * (64u * (uint32_t)vec) + (word % (uint32_t)vec); // lane of bit 0
+    if (lane0 >= n) return; // a column beyond the batch: the step kernel never writes there
+    unsigned long long m[kResetLogRows];
+#pragma unroll
+    for (uint32_t i = 0; i < kResetLogRows; ++i) { // i steps back from the newest pending one; all loads in flight together
+        const uint64_t t = first_tick + pending - 1 - i;
+        m[i] = i < pending ? log[(size_t)((uint32_t)t & (kResetLogRows - 1u)) * row_words + word] : 0ull;
+    }
+    unsigned long long seen = 0, count = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < kResetLogRows; ++i) {
+        if (m[i] == 0) continue;
+        const uint64_t t = first_tick + pending - 1 - i;
+        log[(size_t)((uint32_t)t & (kResetLogRows - 1u)) * row_words + word] = 0; // the ring is all zero between folds
+        count += (unsigned long long)__popcll(m[i]);
+        unsigned long long fresh = m[i] & ~seen;
+        seen |= m[i];
+        while (fresh) {
+            const uint32_t bit = (uint32_t)__ffsll((long long)fresh) - 1u;
+            fresh &= fresh - 1;
+            ep_start[lane0 + (uint64_t)bit * (uint32_t)vec] = (uint32_t)(t + 1); // the next episode started at the next tick
+        }
+    }
+    if (count) atomicAdd(block_stats + (size_t)(word / 4u) * 2, count); // any slot will do: the read-out sums them all
+}
+
+hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, uint64_t first_tick, uint32_t pending, int vec,
+                                 uint32_t* ep_start, uint64_t n, unsigned long long* block_stats, hipStream_t stream)
+{
+    if (pending == 0) return hipSuccess;
+    if (pending >= kResetLogRows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fold_reset_log_kernel, dim3((row_words + kFoldThreads - 1) / kFoldThreads), dim3(kFoldThreads), 0, stream, log, row_words,
+                       first_tick, pending, vec, ep_start, n, block_stats);
     return hipGetLastError();
 }
 

@@ -87,6 +87,12 @@ struct gymrs_engine {
     int trunc_held = -1;         // Pendulum: the uniform value the `truncated` array holds (-1 = unknown: write it)
     unsigned long long* block_stats = nullptr;
     uint32_t n_stat_blocks = 0;
+    // reset log (see StepArgs::reset_log): ring of done-mask rows the per-step kernel writes instead of scattered ep_start
+    // stores; `log_pending` consecutive steps starting at tick `log_first_tick` have rows that are not folded yet
+    unsigned long long* reset_log = nullptr;
+    uint32_t log_row_words = 0, log_pending = 0;
+    uint64_t log_first_tick = 0;
+    int log_vec = 4; // lanes per work-item of the launches that wrote the pending rows
     void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
     size_t pool_bytes = 0;
     int vec = 4; // lanes per work-item
@@ -161,6 +167,9 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.wave_open = e->wave_open;
     a.wave_clean = e->wave_clean;
     a.block_stats = e->block_stats;
+    a.reset_log = e->reset_log;
+    a.reset_log_row_words = e->log_row_words;
+    a.fold_step = 0;
     a.err = e->err;
     a.n = e->n;
     // the vector load of a work-item's actions needs vec * sizeof(action) alignment; any other address is read lane by
@@ -191,6 +200,42 @@ static StatsArgs stats_args(const gymrs_engine* e)
     a.n_steps = e->n_steps_total;
     a.out4 = e->stats_dev;
     return a;
+}
+
+// ---- reset log bookkeeping (host side) ----------------------------------------------------------------------------
+// Invariant: the rows of the steps log_first_tick .. log_first_tick + log_pending - 1 (log_pending < kResetLogRows) may hold
+// bits; every other row of the ring is zero.
+// Fold the pending rows now, with the stand-alone kernel: before anything reads ep_start or the episode counters
+// (statistics, snapshot, clone, the rollout kernel) and when the launch shape changes.
+static gymrs_status fold_reset_log(gymrs_engine* e)
+{
+    if (!e->reset_log || e->log_pending == 0) return GYMRS_OK;
+    HIP_TRY(launch_fold_reset_log(e->reset_log, e->log_row_words, e->log_first_tick, e->log_pending, e->log_vec, e->ep_start, e->n,
+                                  e->block_stats, e->stream));
+    e->log_pending = 0;
+    return GYMRS_OK;
+}
+
+// About to launch ONE per-step kernel at the engine's current tick: *fold = it has to be the folding variant (the ring
+// would be full after it; that launch folds the whole ring inside the kernel, its own masks included).
+static gymrs_status log_before_step(gymrs_engine* e, uint32_t* fold)
+{
+    *fold = 0;
+    if (!e->reset_log) return GYMRS_OK;
+    if (e->log_pending != 0 && e->log_vec != e->vec) { // rows are laid out per wavefront of ONE launch shape
+        if (gymrs_status st = fold_reset_log(e)) return st;
+    }
+    if (e->log_pending == 0) {
+        e->log_first_tick = e->tick;
+        e->log_vec = e->vec;
+    }
+    if (e->log_pending == kResetLogRows - 1) {
+        *fold = 1;
+        e->log_pending = 0;
+    } else {
+        e->log_pending += 1;
+    }
+    return GYMRS_OK;
 }
 
 template <class T>
@@ -330,6 +375,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
     (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
+    (void)hipFree(e->reset_log);
     (void)hipFree(e->wave_open);
     (void)hipFree(e->wave_clean);
     (void)hipFree(e->err);
@@ -473,6 +519,11 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     // workgroups of up to 16 waves
     e->n_stat_blocks = (uint32_t)((((n_envs + 255) / 256) + 15) / 16 * 16);
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
+    if ((flags & GYMRS_TRACK_STATS) && !(flags & GYMRS_TIME_LIMIT) && kind != GYMRS_PENDULUM) {
+        // reset log: kResetLogRows rows of one bit per lane (2^20 lanes: 128 KiB per row)
+        e->log_row_words = e->n_stat_blocks * 4;
+        chk(dev_alloc(&e->reset_log, (size_t)kResetLogRows * e->log_row_words));
+    }
     chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
@@ -493,6 +544,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     e->own_stream = true;
     static const uint32_t err_init[2] = {0u, 0xffffffffu};
     hipError_t merr = hipMemcpyAsync(e->err, err_init, sizeof(err_init), hipMemcpyHostToDevice, e->stream);
+    if (merr == hipSuccess && e->reset_log) merr = hipMemsetAsync(e->reset_log, 0, (size_t)kResetLogRows * e->log_row_words * 8, e->stream);
     if (merr == hipSuccess) merr = hipMemsetAsync(e->truncated, 0, npad, e->stream);
     if (merr == hipSuccess) merr = hipMemsetAsync(e->stats_dev, 0, 4 * sizeof(double), e->stream);
     if (merr != hipSuccess) {
@@ -566,6 +618,7 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
     }
     std::memcpy(e->lo, lo, sizeof(lo));
     std::memcpy(e->hi, hi, sizeof(hi));
+    if (gymrs_status st = fold_reset_log(e)) return st; // leaves the ring all zero; reset_kernel rewrites ep_start below
     // seeding.rs:21-26: the generator is re-created on every reset
     e->seed = has_seed ? seed : os_entropy();
     e->tick = 0;
@@ -635,6 +688,7 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     HIP_TRY(hipSetDevice(e->device));
     if (gymrs_status st = prepare_open_sums(e, e->vec)) return st;
     StepArgs a = step_args(e, actions_dev);
+    if (gymrs_status st = log_before_step(e, &a.fold_step)) return st;
     HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
     e->tick += 1;
     if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
@@ -680,6 +734,7 @@ static gymrs_status rollout_impl(gymrs_engine* e, uint32_t n_steps, uint64_t act
         vec = 4;
     }
     if (gymrs_status st = prepare_open_sums(e, vec)) return st;
+    if (gymrs_status st = fold_reset_log(e)) return st; // the rollout kernel carries ep_start and the counters itself
     HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
     for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
         e->tick += 1;
@@ -731,6 +786,7 @@ static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stri
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         a.tick = t;
         a.tick_base = e->tick_dev;
+        a.fold_step = (e->reset_log && t % kResetLogRows == kResetLogRows - 1) ? 1u : 0u; // a replay starts on an empty ring
         err = launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream);
     }
     if (err == hipSuccess) err = launch_tick_advance(e->tick_dev, steps, e->stream);
@@ -766,8 +822,20 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     const bool graph_ok = use_graph && !(e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT));
     if (use_graph && !graph_ok) return fail(GYMRS_EINVAL, "gymrs_step_many: use_graph is not available for Pendulum with GYMRS_TIME_LIMIT");
     if (graph_ok) {
-        // a graph holds a whole number of passes over the action ring, at least 32 steps
-        const uint32_t per_graph = n_buffers * ((32 + n_buffers - 1) / n_buffers);
+        // a graph holds a whole number of passes over the action ring, at least 32 steps, and (reset-logged engines) a whole
+        // number of ring periods, so that a replay both starts and ends on an empty ring
+        uint32_t passes = (32 + n_buffers - 1) / n_buffers;
+        if (e->reset_log) {
+            uint32_t g = n_buffers, r = kResetLogRows; // gcd
+            while (r) {
+                const uint32_t tmp = g % r;
+                g = r;
+                r = tmp;
+            }
+            const uint32_t unit = kResetLogRows / g;
+            passes = (passes + unit - 1) / unit * unit;
+        }
+        const uint32_t per_graph = n_buffers * passes;
         if (n_steps >= per_graph) {
             const bool hit = e->graph_exec && e->graph_actions == base && e->graph_stride == stride_bytes &&
                              e->graph_nbuf == n_buffers && e->graph_steps == per_graph && e->graph_flags == launch_flags_of(e) &&
@@ -778,6 +846,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
             const unsigned long long tick_now = e->tick;
             HIP_TRY(hipMemcpyAsync(e->tick_dev, &tick_now, sizeof(tick_now), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream)); // tick_now is a stack variable; the copy must finish before return
+            if (gymrs_status st = fold_reset_log(e)) return st; // the captured fold steps assume an empty ring at the start
             while (n_steps - done >= per_graph) {
                 HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
                 done += per_graph;
@@ -787,6 +856,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     }
     for (uint32_t t = done; t < n_steps; ++t) { // eager launches (and the remainder after graph replays)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
+        if (gymrs_status st = log_before_step(e, &a.fold_step)) return st;
         HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
         e->tick += 1;
         if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
@@ -1010,6 +1080,10 @@ gymrs_status gymrs_engine_clone(gymrs_engine* src, gymrs_engine** out)
     gymrs_engine* dst = nullptr;
     if (gymrs_status st = gymrs_engine_create(src->kind, src->n, src->gid0, src->device, nullptr, src->flags, &dst)) return st;
     copy_scalars(dst, src);
+    if (gymrs_status st = fold_reset_log(src)) { // ep_start and the episode counters are copied below
+        gymrs_engine_destroy(dst);
+        return st;
+    }
     hipError_t err = hipStreamSynchronize(src->stream); // everything queued on the source has happened
     const std::vector<Segment> from = snapshot_segments(src), to = snapshot_segments(dst);
     for (size_t i = 0; i < from.size() && err == hipSuccess; ++i)
@@ -1039,6 +1113,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
     (void)gymrs_snapshot_size(e, &need);
     if (bytes < need) return fail(GYMRS_EINVAL, "gymrs_snapshot_save: buffer smaller than gymrs_snapshot_size");
     HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = fold_reset_log(e)) return st; // the blob holds ep_start and the counters, never the log
     SnapshotHeader h;
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, "GYMRSNAP", 8);
@@ -1089,6 +1164,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     if (bytes < need) return fail(GYMRS_EINVAL, "gymrs_snapshot_load: truncated snapshot");
     HIP_TRY(hipSetDevice(e->device));
     drop_graph(e); // seed and reset box are baked into a captured graph
+    if (gymrs_status st = fold_reset_log(e)) return st; // empties the ring; what it folded into is overwritten below
     const char* p = static_cast<const char*>(host_buf) + sizeof(h);
     for (const Segment& sg : snapshot_segments(e)) {
         HIP_TRY(hipMemcpyAsync(sg.dev, p, sg.bytes, hipMemcpyHostToDevice, e->stream));
@@ -1119,6 +1195,7 @@ gymrs_status gymrs_stats_device(gymrs_engine* e, double** dev_out4)
 {
     if (!e || !dev_out4) return fail(GYMRS_EINVAL, "gymrs_stats_device: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = fold_reset_log(e)) return st;
     HIP_TRY(launch_stats(stats_args(e), 0, e->stream));
     *dev_out4 = e->stats_dev;
     return GYMRS_OK;
@@ -1138,6 +1215,7 @@ gymrs_status gymrs_stats_clear(gymrs_engine* e)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_stats_clear: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = fold_reset_log(e)) return st;
     HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
     HIP_TRY(launch_stats(stats_args(e), 1, e->stream));
     e->n_steps_total = 0;
@@ -1455,7 +1533,8 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreate(&ev0);
     if (err == hipSuccess) err = hipEventCreate(&ev1);
-    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+    // warm-up: as many launches again, so that clocks and caches are where a long run has them
+    for (uint32_t i = 0; i < launches + 3 && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
     if (err == hipSuccess) err = hipStreamSynchronize(stream);
     if (err == hipSuccess) err = hipEventRecord(ev0, stream);
     for (uint32_t i = 0; i < launches && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);

@@ -9,6 +9,11 @@ namespace gymrs {
 
 constexpr int kBlock = 256; // work-items per workgroup of the small kernels (reset, fill, statistics) and of the rollout kernel
 constexpr uint32_t kFlagNonTemporal = 0x100u; // internal launch flag (not an engine flag): non-temporal loads/stores
+// Rows of the reset log.  Measured at 2^20 CartPole lanes (128 KiB per row, no folding): a ring of <= 8 rows stays where a
+// write is cheap (6.10 us per launch; 8 steps x 40 MB is about what passes through the 256 MB Infinity Cache before a line
+// is evicted), 16 rows 6.22, >= 32 rows 6.40 (touching the next row one step ahead with a scalar load made it worse:
+// 7.1); the scattered ep_start stores it replaces: 6.65.  Must be a power of two; the folding launch is written for 8.
+constexpr uint32_t kResetLogRows = 8;
 
 // Everything one step() launch needs.  Device pointers are SoA arrays of n lanes.
 struct StepArgs {
@@ -24,6 +29,14 @@ struct StepArgs {
     uint32_t* wave_clean; // [n_waves] constant-reward envs under auto-reset: != 0 = the wave's part of `reward` holds the constant
     double* wave_open;  // [n_waves] Pendulum with GYMRS_TRACK_STATS: per-wavefront sum of the rewards of the open episodes
     unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
+    // Reset log (constant-reward envs with GYMRS_TRACK_STATS and without GYMRS_TIME_LIMIT): instead of one scattered 4-byte
+    // ep_start store per re-armed lane and a read-modify-write of the wavefront's episode counter on every step, a
+    // wavefront that re-armed lanes stores its VEC done-masks (one bit per lane) into row (tick % kResetLogRows) of a small
+    // ring, and every kResetLogRows-th launch (fold_step) each wavefront folds its own column of the ring into ep_start and
+    // its episode counter.  See step_block (gymrs_step_impl.h) and launch_fold_reset_log.
+    unsigned long long* reset_log; // [kResetLogRows][reset_log_row_words]; word (wave * VEC + k), bit = work-item of the wave
+    uint32_t reset_log_row_words;
+    uint32_t fold_step;            // host-side only: launch the folding variant of the kernel
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
     uint64_t n;         // lanes in this engine
     uint64_t n_fast;    // n, or 0 when the action buffer is not aligned for the vector load (step_kernel)
@@ -79,6 +92,11 @@ hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepA
 hipError_t launch_rollout(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const RolloutArgs& r,
                           const void* consts, hipStream_t stream);
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream);
+// Fold the `pending` (< kResetLogRows) not yet folded rows of the reset log (the steps first_tick .. first_tick + pending - 1,
+// lanes-per-work-item `vec`) into ep_start (start tick of every lane's open episode) and the per-wavefront episode
+// counters, and zero them again: on demand, off the hot path (the step kernel folds a full ring itself).
+hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, uint64_t first_tick, uint32_t pending, int vec,
+                                 uint32_t* ep_start, uint64_t n, unsigned long long* block_stats, hipStream_t stream);
 // wave_open[0] += sum of the others, others = 0 (before a launch whose lanes-per-wave differs from the last one's)
 hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream);
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);

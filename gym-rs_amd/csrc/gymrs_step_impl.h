@@ -37,13 +37,31 @@
 
 namespace gymrs {
 
-template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
+// ep = the wave-uniform bit mask `m` (an SGPR pair) selects, per work-item, `fresh` over `ep`: one v_cndmask_b32 with the
+// mask as its condition operand -- a ballot result used the way the hardware uses VCC.
+__device__ __forceinline__ uint32_t select_by_mask(unsigned long long m, uint32_t fresh, uint32_t ep)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(ep), "v"(fresh), "s"(m));
+    return r;
+}
+
+// FOLD (reset-logged variants only): this launch is the kResetLogRows-th since the last fold.  Every wavefront folds ITS
+// OWN column of the ring -- the done-masks of the previous kResetLogRows - 1 steps, one word per lane fetched behind the
+// state loads (they were written by earlier launches), plus this step's masks from registers -- into the start ticks of
+// its own lanes (one dense dwordx4 read-modify-write of ep_start per work-item per kResetLogRows steps; a mask reaches
+// the lanes as the condition operand of one v_cndmask each) and into its episode counter, and zeroes the column.  No
+// extra launch, no scattered store, and the ring stays 8 rows small.  Measured at 2^20 CartPole lanes: a folding launch
+// costs 1.4 us more than a plain one (0.64 of it the ep_start read-modify-write), i.e. 0.17 us per step; per-step time
+// 6.66 us (scattered stores, round 1) -> 6.47 us on the same box.
+template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL, bool FOLD>
 __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds)
 {
     constexpr int kVec = VEC;
     constexpr int LPB = THREADS * kVec;
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
+    constexpr bool LOGGED = TileRegs<Env, VEC, FLAGS>::LOGGED; // bookkeeping through the reset log: no statistics slot to load
     const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * kVec;
     GYMRS_STAMP(0);
     TileRegs<Env, VEC, FLAGS> d;
@@ -59,13 +77,28 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     unsigned long long old_resets = 0;
     double old_ret = 0.0, open = 0.0;
     const size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); // = the global wave index
-    if (STATS) {
+    if (STATS && !LOGGED) {
         const unsigned long long* bs = a.block_stats + wave_slot * 2;
         old_resets = bs[0];
         if (!Env::kConstReward) {
             old_ret = reinterpret_cast<const double*>(bs)[1];
             open = a.wave_open[wave_slot];
         }
+    }
+    // Folding launch: what the fold needs is fetched right behind the state loads -- this work-item's start ticks, the
+    // wave's counter, and the wave's column of the ring: lane i < 7 * VEC fetches word (i % VEC) of the row (i / VEC) + 1
+    // steps back.  (Holding the 28 words in SGPRs from here on made the compiler spill 116 SGPRs: + 1 us per launch.)
+    constexpr int kOlder = (int)kResetLogRows - 1;
+    Vec<uint32_t, VEC> ep;
+    unsigned long long older = 0;
+    [[maybe_unused]] unsigned long long* older_at = nullptr;
+    if constexpr (LOGGED && FOLD) {
+        ep = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
+        const uint32_t lane = threadIdx.x & 63u;
+        older_at = a.reset_log + (size_t)((uint32_t)(a.tick - 1 - (uint64_t)(lane / kVec)) & (kResetLogRows - 1u)) * a.reset_log_row_words +
+                   wave_slot * kVec + lane % kVec;
+        if (lane < (uint32_t)(kOlder * kVec)) older = *older_at;
+        old_resets = a.block_stats[wave_slot * 2];
     }
     // MountainCar pays -1.0 on every step (mountain_car.rs:423; SURVEY 8a row a6 "may be elided ... but counted in
     // algorithmic bytes"): once a wave's part of `reward` holds the constant it is not rewritten until a step pays
@@ -76,8 +109,33 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     if (ELIDE) clean = a.wave_clean[wave_slot];
     GYMRS_STAMP(1);
     StepOut<VEC> out;
-    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out);
+    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS, FOLD>(a, c, base, d, lds, old_resets, old_ret, open, out);
     store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
+    if constexpr (LOGGED && FOLD) {
+        const uint32_t lane = threadIdx.x & 63u;
+        // finished episodes of the wave in the ring's 8 steps: popcounts of the older words (one per lane) and of this step's masks
+        uint32_t finished = wave_sum_u32((uint32_t)__popcll(older));
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) finished += (uint32_t)__popcll(out.masks[k]);
+        if (finished != 0) { // quiet waves (MountainCar: most) leave everything as it is
+#pragma unroll
+            for (int s = kOlder - 1; s >= 0; --s) { // oldest first, so that the most recent re-arm of a lane wins
+                const uint32_t fresh = (uint32_t)(a.tick - (uint64_t)s); // the episode began at the tick after that step
+#pragma unroll
+                for (int k = 0; k < kVec; ++k) {
+                    const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(older >> 32), s * kVec + k) << 32) |
+                                                 (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)older, s * kVec + k);
+                    ep.v[k] = select_by_mask(m, fresh, ep.v[k]);
+                }
+            }
+            const uint32_t fresh_now = (uint32_t)(a.tick + 1);
+#pragma unroll
+            for (int k = 0; k < kVec; ++k) ep.v[k] = select_by_mask(out.masks[k], fresh_now, ep.v[k]);
+            store_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, ep);
+            if (older != 0) *older_at = 0; // zero the column (only lanes < 7 * VEC hold a word)
+            if (lane == 0) a.block_stats[wave_slot * 2] = old_resets + finished;
+        }
+    }
     if (ELIDE && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
     if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
     GYMRS_STAMP(6);
@@ -92,7 +150,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 // THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
-template <class Env, int VEC, uint32_t FLAGS, int THREADS>
+template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FOLD = false>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
     float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs rest,
     const typename Env::Consts c)
@@ -110,26 +168,35 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 /
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
     if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
-        step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, true, FOLD>(a, c, lds);
     else
-        step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, false, FOLD>(a, c, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launch tables
-template <class Env, int VEC, uint32_t FLAGS>
-static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
+template <class Env, int VEC, uint32_t FLAGS, bool FOLD>
+static hipError_t launch_shape(const StepArgs& a, const void* consts, hipStream_t stream)
 {
     if constexpr (Env::kThreads != kBlock) {
         if (a.n >= (uint64_t)Env::kThreads * VEC * 512) { // >= 2 big workgroups per CU
-            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
+            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads, FOLD>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
                                stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock, FOLD>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
                        a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
+}
+
+template <class Env, int VEC, uint32_t FLAGS>
+static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
+{
+    if constexpr (TileRegs<Env, VEC, FLAGS>::LOGGED) { // only the reset-logged variants have a folding form
+        if (a.fold_step) return launch_shape<Env, VEC, FLAGS, true>(a, consts, stream);
+    }
+    return launch_shape<Env, VEC, FLAGS, false>(a, consts, stream);
 }
 
 template <class Env, int VEC, uint32_t NTBIT>
@@ -138,6 +205,11 @@ static hipError_t launch_flags_nt(uint32_t flags, const StepArgs& a, const void*
     constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
     if (!(flags & A)) flags &= ~S; // statistics need auto-reset
     switch (flags & (A | S | T)) {
+#ifdef GYMRS_DEV_MINIMAL // developer builds (tools/devbuild.py): only the headline flag sets, seconds instead of minutes
+    case A | S: return launch_one<Env, VEC, A | S | NTBIT>(a, consts, stream);
+    case A | S | T: return launch_one<Env, VEC, A | S | T | NTBIT>(a, consts, stream);
+    default: return hipErrorInvalidValue;
+#else
     case 0: return launch_one<Env, VEC, 0 | NTBIT>(a, consts, stream);
     case A: return launch_one<Env, VEC, A | NTBIT>(a, consts, stream);
     case A | S: return launch_one<Env, VEC, A | S | NTBIT>(a, consts, stream);
@@ -145,6 +217,7 @@ static hipError_t launch_flags_nt(uint32_t flags, const StepArgs& a, const void*
     case A | T: return launch_one<Env, VEC, A | T | NTBIT>(a, consts, stream);
     case A | S | T: return launch_one<Env, VEC, A | S | T | NTBIT>(a, consts, stream);
     default: return hipErrorInvalidValue;
+#endif
     }
 }
 
@@ -160,7 +233,9 @@ static hipError_t launch_vec(int vec, uint32_t flags, const StepArgs& a, const v
 {
     switch (vec) {
     case 4: return launch_flags<Env, 4>(flags, a, consts, stream);
+#ifndef GYMRS_DEV_MINIMAL
     case 8: return launch_flags<Env, 8>(flags, a, consts, stream);
+#endif
     default: return hipErrorInvalidValue;
     }
 }

@@ -38,6 +38,22 @@ __device__ __forceinline__ float wave_sum(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// The same for an integer (wave-uniform result).
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    auto dpp_add = [](uint32_t x, auto ctrl, auto row_mask) {
+        return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true);
+    };
+    using std::integral_constant;
+    v = dpp_add(v, integral_constant<int, 0xb1>{}, integral_constant<int, 0xf>{});
+    v = dpp_add(v, integral_constant<int, 0x4e>{}, integral_constant<int, 0xf>{});
+    v = dpp_add(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});
+    v = dpp_add(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});
+    v = dpp_add(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+    v = dpp_add(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ---------------------------------------------------------------------------------------------
 // vector access helpers
 template <class T, int V>
@@ -185,6 +201,9 @@ struct TileRegs {
     static constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
     static constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
     static constexpr bool NT = (FLAGS & kFlagNonTemporal) != 0;
+    // Episode bookkeeping of the per-step kernel goes through the reset log (StepArgs::reset_log) when nothing in the
+    // step needs ep_start itself: statistics on, no time limit, constant reward (return = +-length).
+    static constexpr bool LOGGED = STATS && !TLIM && Env::kConstReward;
     Vec<float, VEC> st[Env::kState];
     Vec<typename Env::Action, VEC> act;
     Vec<uint8_t, VEC> beyond;
@@ -243,6 +262,7 @@ struct StepOut {
     Vec<float, VEC> reward;
     Vec<uint8_t, VEC> done, trunc;
     bool reward_is_const; // wave-uniform: every stepped lane of the wave earned Env::kReward (constant-reward envs)
+    unsigned long long masks[VEC]; // wave-uniform: bit i of masks[k] = work-item i re-armed its lane k in this step
 };
 
 // One Env::step() of a tile held in registers: physics + auto-reset of the finished lanes.  The per-step
@@ -253,7 +273,8 @@ struct StepOut {
 // such an env never terminates, so all lanes share one episode clock, finish together, and the return of the
 // finished episodes of a wave is just that sum -- no per-lane return accumulator in HBM (which cost 8 B per
 // lane-step: 29.6 vs 23.4 us per 2^22-lane step).  The caller loads/stores `open` (StepArgs::wave_open).
-template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads>
+// FOLD: a folding launch of a reset-logged per-step kernel (step_block): the step's done-masks stay in registers.
+template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads, bool FOLD = false>
 __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
                                              TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC, THREADS>& lds, unsigned long long& resets,
                                              double& ret, double& open, StepOut<VEC>& out)
@@ -263,6 +284,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
     constexpr int kVec = VEC;
     using R = TileRegs<Env, VEC, FLAGS>;
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
+    constexpr bool LOGGED = R::LOGGED && !ROLL; // the rollout kernel keeps ep_start and its counters in registers
     constexpr int NS = Env::kState;
     using Action = typename Env::Action;
     const uint32_t tick_next = (uint32_t)(a.tick + 1);
@@ -293,6 +315,8 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
         fast = fast && Env::fast_ok(lane_st, la[k]);
     }
     out.reward_is_const = true; // the fast path pays the constant on every lane
+#pragma unroll
+    for (int k = 0; k < kVec; ++k) out.masks[k] = 0;
     if (__all(fast)) { // wave-uniform: the common path
         if (Env::kVariants == 1 || Env::variant(c) == 0)
             advance_fast_all<Env, VEC, 0>(c, ls, la, rw, dn);
@@ -364,6 +388,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
 #pragma unroll
         for (int k = 0; k < kVec; ++k) {
             const unsigned long long m = __ballot(need_reset[k]);
+            out.masks[k] = m;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
             slot[k] = total + rank;
             if (need_reset[k]) {
@@ -372,6 +397,17 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             total += (uint32_t)__popcll(m);
         }
         if (total != 0) { // quiet waves (MountainCar / Pendulum: nearly all) skip everything below
+            if (LOGGED && !FOLD && lane == 0) {
+                // The whole episode bookkeeping of this step for the wave's 64 * VEC lanes: 8 * VEC contiguous bytes.  (Measured at
+                // 2^20 CartPole lanes: the scattered ep_start stores cost 0.45 us per launch -- ~47k partial cache lines -- and the
+                // counter's load + store 0.07; this row entry costs 0.02.)  A folding launch consumes its masks from registers.
+                typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+                const size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + wave;
+                ull2* row = reinterpret_cast<ull2*>(a.reset_log + (size_t)((uint32_t)a.tick & (kResetLogRows - 1u)) * a.reset_log_row_words +
+                                                    wave_slot * kVec);
+#pragma unroll
+                for (int k = 0; k < kVec; k += 2) row[k / 2] = ull2{out.masks[k], out.masks[k + 1]};
+            }
             // DS operations of one wavefront execute in order: no barrier is needed, only the compiler
             // must not move LDS accesses across the hand-over points.
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -386,7 +422,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
 #pragma unroll
                 for (int j = 0; j < NS; ++j) fs.v[j] = ns[j];
                 lds.fresh[wave * LPW + i] = fs;
-                if (!ROLL && (STATS || TLIM)) a.ep_start[gl] = tick_next; // the new episode starts at the next tick (plain
+                if (!ROLL && !LOGGED && (STATS || TLIM)) a.ep_start[gl] = tick_next; // the new episode starts at the next tick (plain
                                                                           // store: a non-temporal scattered dword store measured slower)
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -400,7 +436,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
                     if (ROLL && (STATS || TLIM)) d.ep_start.v[k] = tick_next;
                 }
             }
-            if (STATS) { // the wave's private statistics slot: plain read-modify-write, no atomics
+            if (STATS && !LOGGED) { // the wave's private statistics slot: plain read-modify-write, no atomics
                 unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (THREADS / 64) + wave) * 2;
                 if (!Env::kConstReward) { // every lane of the wave finished (shared clock): the open sum is their return
                     ret += open;
