@@ -519,7 +519,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     // workgroups of up to 16 waves
     e->n_stat_blocks = (uint32_t)((((n_envs + 255) / 256) + 15) / 16 * 16);
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
-    if ((flags & GYMRS_TRACK_STATS) && !(flags & GYMRS_TIME_LIMIT) && kind != GYMRS_PENDULUM) {
+    if ((flags & GYMRS_TRACK_STATS) && !(flags & GYMRS_TIME_LIMIT) && kind == GYMRS_CARTPOLE) { // = TileRegs<CartPoleT, ..>::LOGGED
         // reset log: kResetLogRows rows of one bit per lane (2^20 lanes: 128 KiB per row)
         e->log_row_words = e->n_stat_blocks * 4;
         chk(dev_alloc(&e->reset_log, (size_t)kResetLogRows * e->log_row_words));

@@ -36,7 +36,7 @@ struct StepArgs {
     // its episode counter.  See step_block (gymrs_step_impl.h) and launch_fold_reset_log.
     unsigned long long* reset_log; // [kResetLogRows][reset_log_row_words]; word (wave * VEC + k), bit = work-item of the wave
     uint32_t reset_log_row_words;
-    uint32_t fold_step;            // host-side only: launch the folding variant of the kernel
+    uint32_t fold_step;            // this launch folds the ring (wave-uniform branch in step_block)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
     uint64_t n;         // lanes in this engine
     uint64_t n_fast;    // n, or 0 when the action buffer is not aligned for the vector load (step_kernel)

@@ -29,27 +29,24 @@ GYMRS_HD float clipf(float v, float l, float r)
     return v;
 }
 
-// a / b for a lane-uniform divisor b (total_mass) whose reciprocal rb = fl32(1/b) was rounded once on the
-// host: ONE multiply instead of the 10-instruction IEEE division sequence.  The step kernel is
-// VALU-issue-bound once its loads have landed, so every instruction removed from the
-// per-lane chain is time; the quotient differs from a / b by at most 1 ulp (6e-8 relative), an order of
-// magnitude inside the 1e-6 budget against the f64 oracle, and gfx950 and x86 execute the identical
-// multiply, so the GPU stays bit-identical to its CPU twin.  (Markstein's two-fma correction would
-// recover the correctly rounded a / b for 2 more instructions per division; measured, not worth it.)
-GYMRS_HD float div_by_uniform(float a, float b, float rb)
-{
-    (void)b;
-    return a * rb;
-}
+// Lane-uniform sub-expressions of the CartPole update are folded on the host, in f64, and rounded to f32 ONCE
+// (make_consts): the three divisions by total_mass, polemass_length / total_mass, length * 4/3 and
+// length * masspole / total_mass.  The step kernel is VALU-issue-bound once its loads have landed, so every
+// instruction removed from the per-lane chain is time: 14 f32 operations + one IEEE division per lane-step instead of 19 +
+// one (and of the reference's 3 divisions and 2 powf).  Each folded constant is within half an ulp of the f64 value, each
+// remaining operation rounds once: the state stays <= 3e-7 relative from the f64 oracle's (budget 1e-6, measured in
+// tests/test_twin_vs_oracle.py and on the GPU), and gfx950 and x86 execute the identical operations, so the GPU stays
+// bit-identical to its CPU twin.  The f64 oracle (oracle/gymrs_oracle.c) keeps the reference's exact operation order.
 
 // ---------------------------------------------------------------------------------------------
 // CartPole
 struct CartPoleConsts {
-    float gravity, masspole, length, force_mag, tau;
-    float total_mass;      // masspole + masscart          cartpole.rs:146-148
-    float inv_total_mass;  // fl32(1 / total_mass), for div_by_uniform
-    float polemass_length; // masspole + length (sic, Q1)  cartpole.rs:150-152
-    float four_thirds;     // 4.0/3.0                      cartpole.rs:427
+    float gravity, tau;
+    float force_over_tm;   // force_mag / total_mass                      cartpole.rs:414-418, 423-424
+    float pml_over_tm;     // polemass_length / total_mass, with polemass_length = masspole + length (sic, Q1: cartpole.rs:150-152)
+                           // and total_mass = masspole + masscart (cartpole.rs:146-148)
+    float len_43;          // length * (4.0/3.0)                          cartpole.rs:427
+    float len_mp_over_tm;  // length * masspole / total_mass              cartpole.rs:427-428
     float theta_thr, x_thr;
     int32_t integrator;    // 0 Euler, 1 Other             cartpole.rs:380-387
     uint32_t max_steps;
@@ -58,15 +55,14 @@ struct CartPoleConsts {
 inline CartPoleConsts make_consts(const gymrs_cartpole_params& p)
 {
     CartPoleConsts c;
+    const double total_mass = p.masspole + p.masscart;
+    const double polemass_length = p.masspole + p.length; // the reference ADDS; do not "fix"
     c.gravity = (float)p.gravity;
-    c.masspole = (float)p.masspole;
-    c.length = (float)p.length;
-    c.force_mag = (float)p.force_mag;
     c.tau = (float)p.tau;
-    c.total_mass = (float)(p.masspole + p.masscart);
-    c.inv_total_mass = (float)(1.0 / (double)c.total_mass);
-    c.polemass_length = (float)(p.masspole + p.length); // the reference ADDS; do not "fix"
-    c.four_thirds = (float)(4.0 / 3.0);
+    c.force_over_tm = (float)(p.force_mag / total_mass);
+    c.pml_over_tm = (float)(polemass_length / total_mass);
+    c.len_43 = (float)(p.length * (4.0 / 3.0));
+    c.len_mp_over_tm = (float)(p.length * p.masspole / total_mass);
     c.theta_thr = (float)p.theta_threshold_radians;
     c.x_thr = (float)p.x_threshold;
     c.integrator = p.kinematics_integrator;
@@ -81,17 +77,17 @@ template <class SC = SinCosGeneral, int INTEG = -1>
 GYMRS_HD bool cartpole_advance(const CartPoleConsts& c, float& x, float& x_dot, float& theta, float& theta_dot,
                                uint32_t action)
 {
-    const float force = (action == 1u) ? c.force_mag : -c.force_mag; // :414-418
+    const float force = (action == 1u) ? c.force_over_tm : -c.force_over_tm; // :414-418, already / total_mass
     float sintheta, costheta;
     SC::eval(theta, &sintheta, &costheta); // :420-421
     // :423-424  temp = (force + polemass_length * theta_dot^2 * sintheta) / total_mass
-    const float temp = div_by_uniform(fmaf_(c.polemass_length * (theta_dot * theta_dot), sintheta, force), c.total_mass, c.inv_total_mass);
+    const float temp = fmaf_(c.pml_over_tm, (theta_dot * theta_dot) * sintheta, force);
     // :425-428  thetaacc = (g*sin - cos*temp) / (length * (4/3 - masspole*cos^2/total_mass))
     const float num = fmaf_(-costheta, temp, c.gravity * sintheta);
-    const float den = c.length * (c.four_thirds - div_by_uniform(c.masspole * (costheta * costheta), c.total_mass, c.inv_total_mass));
+    const float den = fmaf_(-c.len_mp_over_tm, costheta * costheta, c.len_43);
     const float thetaacc = num / den;
     // :429  xacc = temp - polemass_length * thetaacc * costheta / total_mass
-    const float xacc = temp - div_by_uniform((c.polemass_length * thetaacc) * costheta, c.total_mass, c.inv_total_mass);
+    const float xacc = fmaf_(-c.pml_over_tm, thetaacc * costheta, temp);
     if (INTEG == 0 || (INTEG < 0 && c.integrator == 0)) { // :431-435 Euler: x and theta advance with the OLD velocities
         x = fmaf_(c.tau, x_dot, x);
         x_dot = fmaf_(c.tau, xacc, x_dot);

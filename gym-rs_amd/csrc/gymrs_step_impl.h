@@ -46,15 +46,17 @@ __device__ __forceinline__ uint32_t select_by_mask(unsigned long long m, uint32_
     return r;
 }
 
-// FOLD (reset-logged variants only): this launch is the kResetLogRows-th since the last fold.  Every wavefront folds ITS
+// StepArgs::fold_step (reset-logged variants only): this launch is the kResetLogRows-th since the last fold.  Every wavefront folds ITS
 // OWN column of the ring -- the done-masks of the previous kResetLogRows - 1 steps, one word per lane fetched behind the
 // state loads (they were written by earlier launches), plus this step's masks from registers -- into the start ticks of
 // its own lanes (one dense dwordx4 read-modify-write of ep_start per work-item per kResetLogRows steps; a mask reaches
 // the lanes as the condition operand of one v_cndmask each) and into its episode counter, and zeroes the column.  No
 // extra launch, no scattered store, and the ring stays 8 rows small.  Measured at 2^20 CartPole lanes: a folding launch
 // costs 1.4 us more than a plain one (0.64 of it the ep_start read-modify-write), i.e. 0.17 us per step; per-step time
-// 6.66 us (scattered stores, round 1) -> 6.47 us on the same box.
-template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL, bool FOLD>
+// 6.66 us (scattered stores, round 1) -> 6.47 us on the same box.  The folding launch is the SAME kernel taking a
+// wave-uniform branch on a kernel argument, not a second instantiation: alternating two kernels (each with its own copy of
+// the physics and reset code) cost MountainCar's 4 us launches up to 1.3 us each.
+template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
 __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds)
 {
     constexpr int kVec = VEC;
@@ -92,7 +94,8 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     Vec<uint32_t, VEC> ep;
     unsigned long long older = 0;
     [[maybe_unused]] unsigned long long* older_at = nullptr;
-    if constexpr (LOGGED && FOLD) {
+    const bool fold = LOGGED && a.fold_step != 0; // wave-uniform (a kernel argument)
+    if (fold) {
         ep = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
         const uint32_t lane = threadIdx.x & 63u;
         older_at = a.reset_log + (size_t)((uint32_t)(a.tick - 1 - (uint64_t)(lane / kVec)) & (kResetLogRows - 1u)) * a.reset_log_row_words +
@@ -109,9 +112,9 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     if (ELIDE) clean = a.wave_clean[wave_slot];
     GYMRS_STAMP(1);
     StepOut<VEC> out;
-    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS, FOLD>(a, c, base, d, lds, old_resets, old_ret, open, out);
+    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out);
     store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
-    if constexpr (LOGGED && FOLD) {
+    if (fold) {
         const uint32_t lane = threadIdx.x & 63u;
         // finished episodes of the wave in the ring's 8 steps: popcounts of the older words (one per lane) and of this step's masks
         uint32_t finished = wave_sum_u32((uint32_t)__popcll(older));
@@ -150,7 +153,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 // THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
-template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FOLD = false>
+template <class Env, int VEC, uint32_t FLAGS, int THREADS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
     float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs rest,
     const typename Env::Consts c)
@@ -168,35 +171,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 /
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
     if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
-        step_block<Env, VEC, FLAGS, THREADS, true, FOLD>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
-        step_block<Env, VEC, FLAGS, THREADS, false, FOLD>(a, c, lds);
+        step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
 // launch tables
-template <class Env, int VEC, uint32_t FLAGS, bool FOLD>
-static hipError_t launch_shape(const StepArgs& a, const void* consts, hipStream_t stream)
+template <class Env, int VEC, uint32_t FLAGS>
+static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
     if constexpr (Env::kThreads != kBlock) {
         if (a.n >= (uint64_t)Env::kThreads * VEC * 512) { // >= 2 big workgroups per CU
-            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads, FOLD>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
+            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
                                stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock, FOLD>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
                        a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
-}
-
-template <class Env, int VEC, uint32_t FLAGS>
-static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
-{
-    if constexpr (TileRegs<Env, VEC, FLAGS>::LOGGED) { // only the reset-logged variants have a folding form
-        if (a.fold_step) return launch_shape<Env, VEC, FLAGS, true>(a, consts, stream);
-    }
-    return launch_shape<Env, VEC, FLAGS, false>(a, consts, stream);
 }
 
 template <class Env, int VEC, uint32_t NTBIT>

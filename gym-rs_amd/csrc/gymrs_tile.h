@@ -110,6 +110,7 @@ struct CartPoleT {
     static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
     static constexpr float kReward = 1.0f;
     static constexpr bool kElideConstReward = false; // measured: +1 % here (VALU-bound; the flag load costs more than 4 B per lane of stores)
+    static constexpr bool kUseResetLog = true;       // measured: 6.67 -> 6.44 us per 2^20-lane step (1 lane in 22 re-arms per step)
     static constexpr bool kHasBeyond = true;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
@@ -121,7 +122,10 @@ struct CartPoleT {
         reward = 1.0f; // the beyond-terminated case is applied by the caller when auto-reset is off
     }
     // branch-free variant, legal when fast_ok holds (|theta| <= pi/4: the polynomial needs no reduction)
-    __device__ static bool fast_ok(const float* st, Action a) { return a < 2 && in_small_range(st[2]); }
+    // A tile is on the fast path when every action is < kActions and the largest range_key of its lanes is <= kRangeMax.
+    static constexpr uint32_t kActions = 2;
+    static constexpr uint32_t kRangeMax = 0x3f490fdbu; // |theta| <= fl32(pi/4); a NaN's bits lie above every bound
+    __device__ static uint32_t range_key(const float* st) { return f2u(st[2]) & 0x7fffffffu; }
     static constexpr int kVariants = 2; // the integrator choice is hoisted out of the per-lane code
     __device__ static int variant(const Consts& c) { return c.integrator == 0 ? 0 : 1; }
     template <int INTEG>
@@ -140,6 +144,8 @@ struct MountainCarT {
     static constexpr bool kConstReward = true; // -1.0 on every step (mountain_car.rs:423)
     static constexpr float kReward = -1.0f;
     static constexpr bool kElideConstReward = true;  // measured: 4.16 -> 3.95 us per 2^20-lane step
+    static constexpr bool kUseResetLog = false;      // measured: 4.16 -> 4.24 .. 4.8 us (re-arms are rare: nearly every wave is
+                                                     // quiet and pays only for the folding launches)
     static constexpr bool kHasBeyond = false;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
@@ -150,7 +156,9 @@ struct MountainCarT {
         done = mountain_car_advance(c, st[0], st[1], a);
         reward = -1.0f;
     }
-    __device__ static bool fast_ok(const float* st, Action a) { return a < 3 && in_short_range(3.0f * st[0]); }
+    static constexpr uint32_t kActions = 3;
+    static constexpr uint32_t kRangeMax = 0x43480000u; // |3 * position| <= 200: f32 Cody-Waite range
+    __device__ static uint32_t range_key(const float* st) { return f2u(3.0f * st[0]) & 0x7fffffffu; }
     static constexpr int kVariants = 1;
     __device__ static int variant(const Consts&) { return 0; }
     template <int>
@@ -169,6 +177,7 @@ struct PendulumT { // spec-derived, not in the reference
     static constexpr bool kConstReward = false;
     static constexpr float kReward = 0.0f; // unused
     static constexpr bool kElideConstReward = false;
+    static constexpr bool kUseResetLog = false;
     static constexpr bool kHasBeyond = false;
     static constexpr bool kHasObsExtra = true;
     // No termination and no invalid actions: every lane's episode clock is the same, so the time limit is a
@@ -181,7 +190,9 @@ struct PendulumT { // spec-derived, not in the reference
         reward = pendulum_advance(c, st[0], st[1], a);
         done = false;
     }
-    __device__ static bool fast_ok(const float* st, Action) { return in_short_range(st[0]); } // |theta| <= 200
+    static constexpr uint32_t kActions = 0;            // a Box action is clipped, never rejected
+    static constexpr uint32_t kRangeMax = 0x43480000u; // |theta| <= 200
+    __device__ static uint32_t range_key(const float* st) { return f2u(st[0]) & 0x7fffffffu; }
     static constexpr int kVariants = 1;
     __device__ static int variant(const Consts&) { return 0; }
     template <int>
@@ -203,7 +214,7 @@ struct TileRegs {
     static constexpr bool NT = (FLAGS & kFlagNonTemporal) != 0;
     // Episode bookkeeping of the per-step kernel goes through the reset log (StepArgs::reset_log) when nothing in the
     // step needs ep_start itself: statistics on, no time limit, constant reward (return = +-length).
-    static constexpr bool LOGGED = STATS && !TLIM && Env::kConstReward;
+    static constexpr bool LOGGED = STATS && !TLIM && Env::kConstReward && Env::kUseResetLog;
     Vec<float, VEC> st[Env::kState];
     Vec<typename Env::Action, VEC> act;
     Vec<uint8_t, VEC> beyond;
@@ -256,6 +267,29 @@ __device__ __forceinline__ void advance_fast_all(const typename Env::Consts& c, 
     }
 }
 
+// Every action of a work-item's packed u8 actions is < N (Discrete(N).contains, discrete.rs:14-19), tested on the dwords:
+// N = 2: no byte has a bit above bit 0; N = 3: no byte has a bit above bit 1 and none is 0b11.  N = 0: nothing to test.
+template <uint32_t N, class A, int VEC>
+__device__ __forceinline__ bool actions_all_below(const Vec<A, VEC>& act)
+{
+    if constexpr (N == 0 || sizeof(A) != 1) {
+        return true;
+    } else {
+        static_assert(N == 2 || N == 3, "only Discrete(2) and Discrete(3) are packed here");
+        struct Words {
+            uint32_t w[VEC / 4];
+        };
+        const Words words = __builtin_bit_cast(Words, act);
+        uint32_t bad = 0;
+#pragma unroll
+        for (int i = 0; i < VEC / 4; ++i) {
+            const uint32_t x = words.w[i];
+            bad |= N == 2 ? (x & 0xfefefefeu) : ((x & 0xfcfcfcfcu) | (x & (x >> 1) & 0x01010101u));
+        }
+        return bad == 0;
+    }
+}
+
 // What one step produces besides the new state in TileRegs.
 template <int VEC>
 struct StepOut {
@@ -273,8 +307,8 @@ struct StepOut {
 // such an env never terminates, so all lanes share one episode clock, finish together, and the return of the
 // finished episodes of a wave is just that sum -- no per-lane return accumulator in HBM (which cost 8 B per
 // lane-step: 29.6 vs 23.4 us per 2^22-lane step).  The caller loads/stores `open` (StepArgs::wave_open).
-// FOLD: a folding launch of a reset-logged per-step kernel (step_block): the step's done-masks stay in registers.
-template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads, bool FOLD = false>
+// a.fold_step: a folding launch of a reset-logged per-step kernel (step_block): the step's done-masks stay in registers.
+template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads>
 __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
                                              TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC, THREADS>& lds, unsigned long long& resets,
                                              double& ret, double& open, StepOut<VEC>& out)
@@ -306,14 +340,18 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GYMRS_STAMP(2); // all loads have landed
 #endif
-    bool fast = FULL;
+    // One compare for the tile's range (max of the lanes' |angle| bit patterns) and one for its packed actions, instead of
+    // two compares per lane.
+    uint32_t key = 0;
 #pragma unroll
     for (int k = 0; k < kVec; ++k) {
         float lane_st[NS];
 #pragma unroll
         for (int j = 0; j < NS; ++j) lane_st[j] = ls[j][k];
-        fast = fast && Env::fast_ok(lane_st, la[k]);
+        const uint32_t kk = Env::range_key(lane_st);
+        key = key > kk ? key : kk;
     }
+    const bool fast = FULL && key <= Env::kRangeMax && actions_all_below<Env::kActions>(d.act);
     out.reward_is_const = true; // the fast path pays the constant on every lane
 #pragma unroll
     for (int k = 0; k < kVec; ++k) out.masks[k] = 0;
@@ -397,7 +435,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
             total += (uint32_t)__popcll(m);
         }
         if (total != 0) { // quiet waves (MountainCar / Pendulum: nearly all) skip everything below
-            if (LOGGED && !FOLD && lane == 0) {
+            if (LOGGED && a.fold_step == 0 && lane == 0) {
                 // The whole episode bookkeeping of this step for the wave's 64 * VEC lanes: 8 * VEC contiguous bytes.  (Measured at
                 // 2^20 CartPole lanes: the scattered ep_start stores cost 0.45 us per launch -- ~47k partial cache lines -- and the
                 // counter's load + store 0.07; this row entry costs 0.02.)  A folding launch consumes its masks from registers.

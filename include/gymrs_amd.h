@@ -265,7 +265,7 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* json, void*
 
 /* ---- measurement ("also measure an in-repo stream-copy kernel on the box") ---------- */
 /* Times `launches` back-to-back launches of a plain dwordx4 copy kernel that reads read_bytes and writes write_bytes
- * per launch (private buffers on `device`, one work-item per 16 bytes, HIP events on a private stream, after as many
+ * per launch (private buffers on `device`, four 16-byte items per work-item like the step kernel's tiles, HIP events on a private stream, after as many
  * untimed warm-up launches) and returns the mean microseconds per launch.  With read/write sizes of one step's traffic this is the
  * floor a step launch of that size can reach on this box (it includes the fixed cost of a dependent launch); with
  * sizes beyond the 256 MiB Infinity Cache it is the HBM bandwidth a kernel can actually get.  non_temporal != 0
