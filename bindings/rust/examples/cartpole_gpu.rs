@@ -24,7 +24,7 @@ fn main() {
     println!("single env: episode return {episode_return}");
 
     // 2. the same random-policy loop for 2^20 envs, 1000 steps each, auto-reset on done
-    let mut batch = Engine::new::<CartPoleParams>(Kind::CartPole, 1 << 20, 0, 0, None, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS);
+    let mut batch = Engine::with_defaults(Kind::CartPole, 1 << 20, 0, 0, GYMRS_AUTO_RESET | GYMRS_TRACK_STATS);
     batch.reset(Some(0), None);
     batch.rollout(1000, 1, 0);
     batch.sync();

@@ -2,7 +2,7 @@
 //!
 //! The pub physics fields can be edited between steps like the reference's; the engine takes its constants
 //! at creation, so an edit is noticed on the next `step`/`reset` and the engine is rebuilt around the current state.
-use crate::engine::{Engine, Kind};
+use crate::engine::Engine;
 use crate::ffi::CartPoleParams;
 use gym_rs::core::{ActionReward, Env, EnvProperties};
 use gym_rs::envs::classical_control::cartpole::{CartPoleObservation, KinematicsIntegrator};
@@ -76,7 +76,7 @@ impl CartPoleEnv {
         assert_eq!(status, 0, "gymrs_default_params");
         let p = unsafe { p.assume_init() };
         let (rng, seed) = rand_random(None);
-        let mut engine = Engine::new(Kind::CartPole, 1, 0, 0, Some(&p), 0);
+        let mut engine = Engine::new(1, 0, 0, &p, 0);
         engine.reset(Some(seed), None);
         let state = observation(&engine.state(0, 1));
         // bounds of cartpole.rs:105-113: twice the thresholds, unbounded velocities
@@ -130,7 +130,8 @@ impl CartPoleEnv {
     fn sync_down(&mut self) {
         let now = self.params_now();
         if now != self.pushed {
-            self.engine = Engine::new(Kind::CartPole, 1, 0, 0, Some(&now), 0);
+            // only the launch constants change: the engine, its device, steps_beyond_terminated, seed and tick stay
+            self.engine.set_params(&now);
             self.pushed = now;
         }
         let host: Vec<f64> = self.state.into();

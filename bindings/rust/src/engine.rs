@@ -28,6 +28,25 @@ impl Kind {
     }
 }
 
+mod sealed {
+    pub trait Sealed {}
+    impl Sealed for crate::ffi::CartPoleParams {}
+    impl Sealed for crate::ffi::MountainCarParams {}
+}
+
+/// The params struct of one env kind.  Sealed: only the two `#[repr(C)]` structs of [`crate::ffi`] implement it, each tied
+/// to its [`Kind`], so a safe caller cannot hand `gymrs_engine_create` a struct of the wrong layout.
+pub trait Params: sealed::Sealed + Copy {
+    /// The env kind these params belong to.
+    const KIND: Kind;
+}
+impl Params for ffi::CartPoleParams {
+    const KIND: Kind = Kind::CartPole;
+}
+impl Params for ffi::MountainCarParams {
+    const KIND: Kind = Kind::MountainCar;
+}
+
 /// The reference has no `Result`s: every failure is a panic (cartpole.rs:402-406, screen.rs:184-203).
 /// So is every non-zero status of the C ABI here.
 fn check(status: c_int) {
@@ -54,15 +73,51 @@ pub struct Engine {
     raw: *mut ffi::GymrsEngine,
     kind: Kind,
     n: u64,
+    device: i32,
 }
 
 impl Engine {
-    /// `gymrs_engine_create`.  `params` must be the params struct matching `kind` (or `None` for the defaults).
-    pub fn new<P>(kind: Kind, n_envs: u64, global_env_offset: u64, device: i32, params: Option<&P>, flags: u32) -> Self {
+    /// `gymrs_engine_create` with the kind's default constants.
+    pub fn with_defaults(kind: Kind, n_envs: u64, global_env_offset: u64, device: i32, flags: u32) -> Self {
         let mut raw = std::ptr::null_mut();
-        let p = params.map_or(std::ptr::null(), |p| p as *const P as *const c_void);
-        check(unsafe { ffi::gymrs_engine_create(kind.raw(), n_envs, global_env_offset, device, p, flags, &mut raw) });
-        Engine { raw, kind, n: n_envs }
+        check(unsafe { ffi::gymrs_engine_create(kind.raw(), n_envs, global_env_offset, device, std::ptr::null(), flags, &mut raw) });
+        Engine { raw, kind, n: n_envs, device }
+    }
+
+    /// `gymrs_engine_create`; the env kind follows from the params type.
+    pub fn new<P: Params>(n_envs: u64, global_env_offset: u64, device: i32, params: &P, flags: u32) -> Self {
+        let mut raw = std::ptr::null_mut();
+        check(unsafe {
+            ffi::gymrs_engine_create(P::KIND.raw(), n_envs, global_env_offset, device, params as *const P as *const c_void, flags, &mut raw)
+        });
+        Engine { raw, kind: P::KIND, n: n_envs, device }
+    }
+
+    /// Assign the pub physics fields of every lane (`gymrs_set_params`): only the constants change -- state,
+    /// `steps_beyond_terminated`, the episode clock, seed and tick carry on, exactly like `env.gravity = ..` on the
+    /// reference struct between two `step()` calls (cartpole.rs:455-464 reads the fields afresh on every step).
+    pub fn set_params<P: Params>(&mut self, params: &P) {
+        assert_eq!(P::KIND, self.kind, "params of another env kind");
+        check(unsafe { ffi::gymrs_set_params(self.raw, params as *const P as *const c_void) });
+    }
+
+    /// The GPU this engine lives on.
+    pub fn device(&self) -> i32 {
+        self.device
+    }
+
+    /// What `serde_json::to_string(&env)` prints for the reference env that lane `lane` stands for (`gymrs_env_json`).
+    pub fn env_json(&mut self, lane: u64) -> String {
+        let mut need = 0u64;
+        let mut buf = vec![0u8; 2048];
+        let mut st = unsafe { ffi::gymrs_env_json(self.raw, lane, buf.as_mut_ptr() as *mut _, buf.len() as u64, &mut need) };
+        if st != ffi::GYMRS_OK && need as usize > buf.len() {
+            buf = vec![0u8; need as usize];
+            st = unsafe { ffi::gymrs_env_json(self.raw, lane, buf.as_mut_ptr() as *mut _, buf.len() as u64, &mut need) };
+        }
+        check(st);
+        let end = buf.iter().position(|b| *b == 0).unwrap_or(buf.len());
+        String::from_utf8_lossy(&buf[..end]).into_owned()
     }
 
     /// Number of lanes.
@@ -174,7 +229,7 @@ impl Clone for Engine {
     fn clone(&self) -> Self {
         let mut raw = std::ptr::null_mut();
         check(unsafe { ffi::gymrs_engine_clone(self.raw, &mut raw) });
-        Engine { raw, kind: self.kind, n: self.n }
+        Engine { raw, kind: self.kind, n: self.n, device: self.device }
     }
 }
 

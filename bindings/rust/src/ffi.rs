@@ -1,4 +1,4 @@
-//! Raw declarations of `include/gymrs_amd.h` (ABI version 1).  Field order and types follow the header.
+//! Raw declarations of `include/gymrs_amd.h` (ABI version 2).  Field order and types follow the header.
 #![allow(missing_docs)]
 use std::os::raw::{c_char, c_int, c_void};
 
@@ -106,4 +106,9 @@ extern "C" {
     pub fn gymrs_snapshot_size(e: *mut GymrsEngine, bytes: *mut u64) -> c_int;
     pub fn gymrs_snapshot_save(e: *mut GymrsEngine, host_buf: *mut c_void, bytes: u64) -> c_int;
     pub fn gymrs_snapshot_load(e: *mut GymrsEngine, host_buf: *const c_void, bytes: u64) -> c_int;
+    // ABI 2
+    pub fn gymrs_set_params(e: *mut GymrsEngine, params: *const c_void) -> c_int;
+    pub fn gymrs_get_params(e: *mut GymrsEngine, params_out: *mut c_void) -> c_int;
+    pub fn gymrs_env_json(e: *mut GymrsEngine, lane: u64, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
+    pub fn gymrs_params_from_json(kind: c_int, json: *const c_char, params: *mut c_void, state: *mut f64, state_dim: *mut c_int) -> c_int;
 }

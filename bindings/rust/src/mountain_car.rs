@@ -1,5 +1,5 @@
 //! `MountainCarEnv` with the reference's public surface (mountain_car.rs:46-80, 392-530), one GPU lane behind it.
-use crate::engine::{Engine, Kind};
+use crate::engine::Engine;
 use crate::ffi::MountainCarParams;
 use gym_rs::core::{ActionReward, Env, EnvProperties};
 use gym_rs::envs::classical_control::mountain_car::MountainCarObservation;
@@ -60,7 +60,7 @@ impl MountainCarEnv {
         assert_eq!(status, 0, "gymrs_default_params");
         let p = unsafe { p.assume_init() };
         let (rng, seed) = rand_random(None);
-        let mut engine = Engine::new(Kind::MountainCar, 1, 0, 0, Some(&p), 0);
+        let mut engine = Engine::new(1, 0, 0, &p, 0);
         engine.reset(Some(seed), None);
         let state = observation(&engine.state(0, 1));
         MountainCarEnv {
@@ -103,7 +103,8 @@ impl MountainCarEnv {
     fn sync_down(&mut self) {
         let now = self.params_now();
         if now != self.pushed {
-            self.engine = Engine::new(Kind::MountainCar, 1, 0, 0, Some(&now), 0);
+            // only the launch constants change: the engine, its device, steps_beyond_terminated, seed and tick stay
+            self.engine.set_params(&now);
             self.pushed = now;
         }
         let st = [self.state.position.into_inner() as f32, self.state.velocity.into_inner() as f32];

@@ -140,14 +140,20 @@ static uint64_t os_entropy()
     return ((uint64_t)rd() << 32) ^ (uint64_t)rd();
 }
 
-// Non-temporal accesses pay off while one step's arrays (state in + out, rewards, flags) are small next to
-// the 256 MB Infinity Cache; beyond that the cache serving the next step's reads is worth more (measured:
-// CartPole 2^20 lanes 7.2 vs 7.5 us, 2^22 lanes 30 vs 26 us).  Threshold: 48 MiB of per-step traffic.
+// Memory hints (measured, tools/size_sweep.py, profiles/r02_size_sweep.log).  Non-temporal accesses pay off
+//   * while one step's arrays (state in + out, rewards, flags) are small next to the 256 MB Infinity Cache (CartPole 2^20
+//     lanes: 6.6 vs 7.0 us): every array is read once and written once per step and the next reader is the next kernel;
+//   * and again once one step's traffic is well beyond the cache (>= ~340 MiB: CartPole 2^24 lanes 111 vs 117 us,
+//     MountainCar 2^24 lanes 52 vs 57 us): nothing survives until the next step anyway and the streaming hint spares
+//     the cache the churn.
+// In between (2^21 .. 2^23 CartPole lanes) the Infinity Cache serves part of the next step's reads and plain accesses
+// win (2^22 lanes: 25.6 vs 30.1 us).
 static uint32_t launch_flags_of(const gymrs_engine* e)
 {
     const uint64_t bytes_per_lane = (uint64_t)e->state_dim * 8 + 10 + (e->kind == GYMRS_PENDULUM ? 8 : 0);
-    const bool small = e->n * bytes_per_lane <= (48ull << 20);
-    const bool nt = e->nt_mode == 1 || (e->nt_mode == 0 && small);
+    const uint64_t per_step = e->n * bytes_per_lane;
+    const bool streaming = per_step <= (48ull << 20) || per_step >= (340ull << 20);
+    const bool nt = e->nt_mode == 1 || (e->nt_mode == 0 && streaming);
     return e->flags | (nt ? kFlagNonTemporal : 0u);
 }
 

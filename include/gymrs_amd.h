@@ -282,7 +282,8 @@ gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t see
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
 /* Kernel tuning knobs for benchmarks; results never depend on them.  lanes_per_thread: 4 (default) or 8
  * lanes per work-item (16 was measured 4x slower everywhere and was removed in ABI 2).  memory_hint: 0 = automatic (non-temporal loads/stores while one step's traffic is
- * <= 48 MiB), 1 = always non-temporal, 2 = never. */
+ * <= 48 MiB or >= 340 MiB; plain in between, where the Infinity Cache still serves part of the next step), 1 = always
+ * non-temporal, 2 = never. */
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint);
 
 const char* gymrs_last_error(void);
