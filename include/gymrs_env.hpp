@@ -140,6 +140,23 @@ public:
     {
         check(gymrs_get_step_result(e_, first, count, reward, done, truncated));
     }
+    // the pub physics fields after construction (cartpole.rs:53-82): only the constants change, the episode carries on
+    void set_params(const void* params) { check(gymrs_set_params(e_, params)); }
+    void get_params(void* params_out) { check(gymrs_get_params(e_, params_out)); }
+    // `#[derive(Serialize)]` view of the reference env lane `lane` stands for (core.rs:25)
+    std::string to_json(std::uint64_t lane = 0)
+    {
+        std::uint64_t need = 0;
+        std::string buf(2048, '\0');
+        gymrs_status st = gymrs_env_json(e_, lane, buf.data(), buf.size(), &need);
+        if (st != GYMRS_OK && need > buf.size()) {
+            buf.assign(need, '\0');
+            st = gymrs_env_json(e_, lane, buf.data(), buf.size(), &need);
+        }
+        check(st);
+        buf.resize(need ? need - 1 : 0);
+        return buf;
+    }
     gymrs_engine* handle() { return e_; }
     std::uint64_t size() const { return n_; }
     int state_dim() const { return state_dim_; }
@@ -194,11 +211,22 @@ public:
         const float s[4] = {(float)o.x, (float)o.x_dot, (float)o.theta, (float)o.theta_dot};
         env_.set_state(0, 1, s);
     }
+    // The reference's constants are pub fields (cartpole.rs:53-82): read them all, edit, assign them back.  Like the
+    // assignment in Rust this changes nothing but the constants (state, steps_beyond_terminated, seed/tick carry on).
+    gymrs_cartpole_params params()
+    {
+        gymrs_cartpole_params p;
+        env_.get_params(&p);
+        return p;
+    }
+    void set_params(const gymrs_cartpole_params& p) { env_.set_params(&p); }
+    std::string to_json() { return env_.to_json(0); } // serde_json::to_string(&env)
     Discrete action_space() const { return Discrete{2}; } // cartpole.rs:114
-    BoxR<Observation> observation_space() const         // cartpole.rs:105-115
+    BoxR<Observation> observation_space()               // cartpole.rs:105-115
     {
         const double inf = std::numeric_limits<double>::infinity();
-        const Observation high{2.4 * 2., inf, (12. * 2. * 3.14159265358979323846 / 360.) * 2., inf};
+        const gymrs_cartpole_params p = params();
+        const Observation high{p.x_threshold * 2., inf, p.theta_threshold_radians * 2., inf};
         return {-high, high};
     }
     RewardRange reward_range() const { return {}; }
@@ -254,6 +282,14 @@ public:
         const float s[2] = {(float)o.position, (float)o.velocity};
         env_.set_state(0, 1, s);
     }
+    gymrs_mountain_car_params params()
+    {
+        gymrs_mountain_car_params p;
+        env_.get_params(&p);
+        return p;
+    }
+    void set_params(const gymrs_mountain_car_params& p) { env_.set_params(&p); }
+    std::string to_json() { return env_.to_json(0); }
     Discrete action_space() const { return Discrete{3}; }                                    // mountain_car.rs:362
     BoxR<Observation> observation_space() const { return {{-1.2, -0.07}, {0.6, 0.07}}; }      // :353-364
 

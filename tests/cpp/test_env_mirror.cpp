@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "gymrs_env.hpp"
 
@@ -34,6 +35,23 @@ int main()
         auto ar = env.step(1);
         REQUIRE(close_to(ar.observation.x_dot, 0.35615076996399875, 1e-6) && close_to(ar.observation.theta_dot, -0.2430694901285738, 1e-6));
         REQUIRE(ar.reward == 1.0 && !ar.done && !ar.truncated && ar.info.has_value());
+        // assigning a pub physics field keeps the episode: the terminating step pays 1.0, the next one 0.0 even though
+        // gravity was changed in between (cartpole.rs:455-464); the serde view carries the reference's field names
+        env.set_state({2.39, 3.0, 0.0, 0.0});
+        auto term = env.step(1);
+        REQUIRE(term.done && term.reward == 1.0);
+        auto p = env.params();
+        REQUIRE(p.gravity == 9.8);
+        p.gravity = 19.6;
+        env.set_params(p);
+        REQUIRE(env.params().gravity == 19.6);
+        auto beyond = env.step(1);
+        REQUIRE(beyond.done && beyond.reward == 0.0);
+        const std::string js = env.to_json();
+        REQUIRE(js.find("\"gravity\":19.6") != std::string::npos && js.find("\"steps_beyond_terminated\":0") != std::string::npos);
+        REQUIRE(js.find("\"kinematics_integrator\":\"Euler\"") != std::string::npos);
+        p.gravity = 9.8;
+        env.set_params(p);
         // trajectories: always 1 -> 10 steps, always 0 -> 9, alternate 1,0,... -> 60
         const int expect[3] = {10, 9, 60};
         for (int p = 0; p < 3; ++p) {

@@ -3,6 +3,8 @@
 
     python tools/summarize_rocprof.py kernel  <results.db> <out.txt>     # --kernel-trace --stats summary
     python tools/summarize_rocprof.py traffic <fetch.db> <write.db> <env> <out.json>   # PMC FETCH_SIZE / WRITE_SIZE
+    python tools/summarize_rocprof.py counters <results.db> <out.txt> [kernel-substring] [title]   # any --pmc pass: per-launch averages
+    python tools/summarize_rocprof.py valu <results.db> <key> <lanes> <steps_per_launch> <sha16> <out.json>   # SQ_INSTS_VALU of the rollout kernel
 """
 import json
 import sqlite3
@@ -61,8 +63,50 @@ def traffic(fetch_db, write_db, env, out):
     print(json.dumps(data[env], indent=1))
 
 
+def counters(db, out, pattern="step_kernel", title=""):
+    c = sqlite3.connect(db)
+    rows = c.execute("select counter_name, count(*), avg(value), min(value), max(value) from counters_collection where kernel_name like ? "
+                     "group by counter_name order by counter_name", (f"%{pattern}%",)).fetchall()
+    k = c.execute("select kernel_name, grid_size, workgroup_size from counters_collection where kernel_name like ? limit 1", (f"%{pattern}%",)).fetchone()
+    lines = [title or f"rocprofv3 --pmc per-launch averages, kernels matching '{pattern}'", f"source: {db}"]
+    waves = None
+    if k:
+        try:
+            waves = int(k[1]) // 64
+            lines.append(f"kernel: {k[0][:160]}")
+            lines.append(f"grid {k[1]} work-items, workgroup {k[2]} -> {waves} waves per launch")
+        except Exception:
+            waves = None
+    lines.append("")
+    for name, n, avg, mn, mx in rows:
+        per_wave = f"  per_wave={avg / waves:10.1f}" if waves else ""
+        lines.append(f"{name:28s} launches={n:5d} avg={avg:16.1f} min={mn:14.1f} max={mx:14.1f}{per_wave}")
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+def valu(db, key, lanes, steps_per_launch, sha, out):
+    c = sqlite3.connect(db)
+    r = c.execute("select count(*), avg(value) from counters_collection where kernel_name like '%rollout_kernel%' and counter_name = 'SQ_INSTS_VALU'").fetchone()
+    try:
+        data = json.load(open(out))
+        if data.get("kernel_source_sha16") != sha:
+            data = {}
+    except Exception:
+        data = {}
+    data["kernel_source_sha16"] = sha
+    data[key] = {"SQ_INSTS_VALU_per_launch": r[1], "launches": r[0], "lanes": int(lanes), "steps_per_launch": int(steps_per_launch),
+                 "source": db}
+    json.dump(data, open(out, "w"), indent=1)
+    print(key, data[key])
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernel":
         kernel_summary(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "counters":
+        counters(*sys.argv[2:])
+    elif sys.argv[1] == "valu":
+        valu(*sys.argv[2:])
     else:
         traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
