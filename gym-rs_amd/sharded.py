@@ -169,24 +169,26 @@ class ShardedRun:
             return self.allreduce_path
         self.allreduce_path = f"torch.distributed({self.coll.backend})"
         if prefer_native and hasattr(self.engine, "comm_init"):
-            err = None
-            uid = None
-            if self.info.is_root:
-                try:
-                    uid = self.engine.comm_unique_id()
-                except Exception as exc:  # librccl missing: every rank must take the same fallback
-                    err = repr(exc)
-            uid, err = self.coll.broadcast_from_root((uid, err))
+            # 1. every rank checks that it can reach the library's RCCL entry points at all (a rank that cannot must not
+            #    leave the others waiting inside ncclCommInitRank); rank 0's id is the one that is used
+            uid, err = None, None
+            try:
+                uid = self.engine.comm_unique_id()
+            except Exception as exc:  # librccl missing on this rank
+                err = repr(exc)
+            if self.coll.sum([0.0 if err else 1.0])[0] != float(self.info.world):
+                self.allreduce_note = f"native RCCL path unavailable on at least one rank: {err}"
+                return self.allreduce_path
+            # 2. rank 0's 128 bytes travel through the torch.distributed store; every rank joins
+            uid = self.coll.broadcast_from_root(uid)
             ok = 0.0
-            if err is None:
-                try:
-                    self.engine.comm_init(self.info.world, self.info.rank, uid)
-                    ok = 1.0
-                except Exception as exc:
-                    err = repr(exc)
-            # all ranks or none: a communicator half the ranks joined would hang the first collective
-            all_ok = self.coll.sum([ok])[0] == float(self.info.world)
-            if all_ok:
+            try:
+                self.engine.comm_init(self.info.world, self.info.rank, uid)
+                ok = 1.0
+            except Exception as exc:
+                err = repr(exc)
+            # 3. all ranks or none: a communicator only part of the ranks hold must never see a collective
+            if self.coll.sum([ok])[0] == float(self.info.world):
                 self.allreduce_path = "gymrs_allreduce_stats (RCCL via the C ABI)"
             else:
                 self.allreduce_note = f"native RCCL path unavailable: {err}"
