@@ -345,9 +345,18 @@ def run_rank(args, info, backend, make_collective=None):
         run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
     backend.sync()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps)  # first calibration pass: clocks may still be ramping up after a short warm-up
     backend.sync()
-    passes = choose_passes(time.perf_counter() - t0)
+    first = time.perf_counter() - t0
+    again = min(choose_passes(first, 2e-3), 64)  # ~2 ms more, then the rate is the warm one
+    if os.environ.get("GYMRS_BENCH_PASSES"):      # tests pin the amount of work to compare two runs' statistics
+        again = 1
+    again = int(coll.max([again])[0])             # every rank steps the same number of times
+    t0 = time.perf_counter()
+    for _ in range(again):
+        run_steps(args.steps)
+    backend.sync()
+    passes = choose_passes((time.perf_counter() - t0) / again)
     if os.environ.get("GYMRS_BENCH_PASSES"):  # tests pin the amount of work to compare two runs' statistics
         passes = max(1, int(os.environ["GYMRS_BENCH_PASSES"]))
     passes = int(coll.max([passes])[0])  # every rank times the same work
@@ -405,6 +414,7 @@ def run_rank(args, info, backend, make_collective=None):
             "timing": {
                 "repetitions": reps,
                 "passes_per_repetition": passes,
+                "calibration_passes": 1 + again,  # untimed passes of K steps between the warm-up and the first repetition
                 "steps_per_repetition": steps_timed,
                 "wall_ms_per_repetition": [w * 1e3 for w in walls],
                 "event_ms_per_repetition": kernels,

@@ -22,7 +22,7 @@ def run(cmd, env=None):
     return json.loads(lines[0])
 
 
-def check_common(d, n_gpus, steps, warmup, min_ms=4.0):
+def check_common(d, n_gpus, steps, warmup, min_ms=3.5):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "timing"):
         assert key in d, key
@@ -108,6 +108,7 @@ def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     assert two["oversubscribed"] and two["config"]["stats_allreduce"] == "torch.distributed(gloo)"
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", "200000", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == two["timing"]["passes_per_repetition"] == 3
+    assert one["timing"]["calibration_passes"] == two["timing"]["calibration_passes"]
     assert one["episodes"] == two["episodes"] and one["episodes"]["n_episodes"] > 0
 
 

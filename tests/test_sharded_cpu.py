@@ -156,7 +156,8 @@ def test_bench_rank_logic_two_ranks_gloo(tmp_path, twin):
             full.step(ring[t % 4])
 
     run(warmup)
-    run(steps)  # bench's calibration pass
+    for _ in range(out["timing"]["calibration_passes"]):  # bench's untimed calibration passes
+        run(steps)
     full.stats_clear()
     for _ in range(reps * passes):
         run(steps)
