@@ -155,3 +155,44 @@ def test_cpp_trait_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
         pytest.skip("a GPU is present: the run is covered by tests/test_gpu_envs.py::test_cpp_trait_mirror")
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert res.returncode != 0 and "no CPU fallback" in (res.stdout + res.stderr)
+
+
+def test_header_is_plain_c_and_links_from_gcc(tmp_path):
+    """The drop-in boundary is a C ABI: include/gymrs_amd.h must compile as pedantic C99 (no C++, no HIP or torch types
+    in the signatures) and a gcc-built caller must link against the library."""
+    src = tmp_path / "caller.c"
+    src.write_text(r'''
+#include "gymrs_amd.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    gymrs_cartpole_params p;
+    gymrs_mountain_car_params m;
+    double state[4];
+    int dim = -1;
+    if (gymrs_default_params(GYMRS_CARTPOLE, &p) != GYMRS_OK || gymrs_default_params(GYMRS_MOUNTAIN_CAR, &m) != GYMRS_OK) return 1;
+    if (gymrs_params_from_json(GYMRS_CARTPOLE, "{\"gravity\":3.5,\"kinematics_integrator\":\"Other\",\"state\":{\"x\":1,\"x_dot\":2,\"theta\":3,\"theta_dot\":4}}",
+                               &p, state, &dim) != GYMRS_OK) return 2;
+    printf("%d %.17g %.17g %d %d %.1f\n", gymrs_abi_version(), p.gravity, p.theta_threshold_radians, p.kinematics_integrator, dim, state[3]);
+    if (gymrs_params_from_json(GYMRS_CARTPOLE, "[1,2]", &p, NULL, NULL) != GYMRS_EINVAL) return 3;
+    return strstr(gymrs_last_error(), "not a JSON object") ? 0 : 4;
+}
+''')
+    exe = tmp_path / "caller"
+    lib_dir = ROOT / "gym-rs_amd"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+                    f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, text=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.split() == ["2", "3.5", "0.20943951023931953", "1", "4", "4.0"]
+
+
+def test_params_from_json_keeps_missing_keys_and_rejects_wrong_types(gymrs):
+    p, state = gymrs.params_from_json(gymrs.MOUNTAIN_CAR, '{"force": 0.002, "gymrs": {"max_episode_steps": 321}, "unknown": [1, {"a": null}]}')
+    d = gymrs.engine.default_params(gymrs.MOUNTAIN_CAR)
+    assert p.force == 0.002 and p.max_episode_steps == 321 and p.gravity == d.gravity and state is None
+    p, state = gymrs.params_from_json(gymrs.PENDULUM, '{"g": 9.81, "state": {"theta": 0.5, "theta_dot": null}}')
+    assert p.g == 9.81 and state[0] == 0.5 and state[1] != state[1]  # null = a non-finite float in serde_json's output
+    for bad in ('{"gravity": "x"}', '{"gravity": 1,}', "", '{"kinematics_integrator": "RK4"}', '{"state": 3}'):
+        with pytest.raises(gymrs.GymrsError):
+            gymrs.params_from_json(gymrs.CARTPOLE, bad)
