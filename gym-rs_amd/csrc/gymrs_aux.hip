@@ -1,6 +1,6 @@
 // gymrs_aux.hip -- the kernels OFF the per-step path: Env::reset for every lane, the synthetic random-policy action
 // stream, the statistics read-out, and two one-thread helpers.  Kept in their own translation unit so that the
-// step-kernel table (gymrs_kernels.hip, minutes of compile time) is not rebuilt when one of these changes.
+// step-kernel tables (gymrs_step_<env>.hip) are not rebuilt when one of these changes.
 #include "gymrs_tile.h"
 
 namespace gymrs {

@@ -1,5 +1,5 @@
 // gymrs_kernels.h — launch interface between the engine (gymrs_engine.hip) and the gfx950 kernels
-// (gymrs_kernels.hip).  Plain structs passed by value as kernel arguments (uniform -> SGPRs).
+// (gymrs_step_<env>.hip, gymrs_rollout.hip, gymrs_aux.hip).  Plain structs passed by value as kernel arguments (uniform -> SGPRs).
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -12,7 +12,7 @@
 //   * SoA f32 state in HBM; a work-item owns 4 consecutive lanes and moves them with one dwordx4
 //     load + store per array (16 B per work-item, 1 KiB per wave instruction); actions and done flags
 //     travel as one packed dword.
-//   * A 2^20-lane launch is ONE generation of waves (1024 workgroups x 4 wave64, all resident): every
+//   * A 2^20-lane launch is ONE generation of waves (CartPole: 512 workgroups x 8 wave64, all resident): every
 //     wave loads, computes, stores once.  The kernel time is launch + memory round trip + whatever
 //     VALU work and latency sit between a wave's last load and its stores.
 //   * The physics of the 4 lanes of a work-item runs as ONE basic block whenever the whole wave is on
@@ -28,10 +28,14 @@
 //     slower on MountainCar: its barrier re-couples the waves), no speculative evaluation (Philox in the
 //     load shadow measured no better: v_mad_u64_u32 is quarter rate and the shadow is not free).
 //     Quiet waves (MountainCar, Pendulum: nearly all) skip the whole path.
-//   * Episode statistics cost the step nothing it can wait on: a re-armed lane's worker only WRITES the
-//     tick its next episode starts at (episodes tile a lane's time axis, so the sum of finished lengths
-//     is sum(ep_start) - n*epoch, evaluated when statistics are read) and every wave keeps a private
-//     episode counter slot (plain load at start, plain store at end; no atomics).
+//   * Episode bookkeeping: what a step has to remember is the tick each lane's open episode started at (episodes tile a
+//     lane's time axis, so the sum of finished lengths is sum(ep_start) - n*epoch, evaluated when statistics are read)
+//     and the number of finished episodes.  Every vector memory instruction of a wave costs 0.05-0.1 us of launch
+//     time here, and a partial-line write is cheap only while its line is in the Infinity Cache: scattered ep_start
+//     stores cost 0.45 us per launch, a counter's load + store 0.07.  CartPole (statistics on, no time limit) therefore
+//     keeps a RESET LOG: a wave stores its VEC done-masks (32 contiguous bytes) into an 8-row ring and every 8th launch
+//     folds the ring inside the kernel (step_block below).  The other variants keep the scattered stores (after a dense
+//     ep_start read of the same wave they hit) and a per-wave counter slot (plain load at start, plain store at end).
 #pragma once
 #include "gymrs_tile.h"
 
@@ -144,8 +148,8 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     GYMRS_STAMP(6);
 }
 
-// VEC lanes per work-item: 4 (1024 workgroups for 2^20 lanes, 4 waves per SIMD), 8 (2 waves per SIMD) or 16
-// (1 wave per SIMD).  More lanes per wave = fewer waves = fewer per-wave fixed costs (address set-up, the
+// VEC lanes per work-item: 4 (4096 waves for 2^20 lanes, 4 waves per SIMD) or 8 (2 waves per SIMD; a tuning knob: measured
+// 9.9 vs 6.8 us; 16 lanes, 28 us, were removed).  More lanes per wave = fewer waves = fewer per-wave fixed costs (address set-up, the
 // auto-reset Philox pass, which costs the same whether 11 or 45 of its 64 lanes are active) at the price of
 // registers; waves_per_eu lets the allocator use them instead of spilling to chase occupancy.
 // The pointers and the lane count the first instructions of a wave need are separate scalar kernel parameters

@@ -1,4 +1,4 @@
-// gymrs_tile.h -- device code shared by the per-step kernel (gymrs_kernels.hip) and the fused rollout kernel
+// gymrs_tile.h -- device code shared by the per-step kernel (gymrs_step_impl.h) and the fused rollout kernel
 // (gymrs_rollout.hip): the env policies, the register tile of a work-item, and one Env::step() of that tile
 // (physics + wave-level auto-reset).  gfx950 device code only.
 #pragma once
