@@ -6,6 +6,8 @@
  * Every function cites the reference lines it restates.  Parity status: step/reset physics
  * "parity unpinned" by the reference's own tests (it has none for them); clip / contains /
  * seed echo are pinned.  Pendulum is spec-derived (not in the reference).
+ * The one-command pin by the reference itself (needs a Rust toolchain, absent here): bindings/rust/src/bin/make_golden.rs
+ * runs gym-rs' own step()/reset() on the fixture inputs; tests/test_oracle_reference_pins.py then holds this file to it.
  */
 #include "gymrs_oracle.h"
 
