@@ -123,7 +123,13 @@ class _SingleEnv:
         return None
 
     def close(self) -> None:
-        """``Env::close`` (core.rs:56)."""
+        """``Env::close`` (core.rs:56; cartpole.rs:534-536, mountain_car.rs:503-505): the reference only drops its GUI
+        handle (screen.rs:80-82) and the env stays steppable -- examples/mountain_car.rs:30-37 steps 200 more times
+        after ``close()``.  There is no GUI here, so this is a no-op; ``release()`` (or dropping the object) frees the
+        GPU lane."""
+
+    def release(self) -> None:
+        """Free the device memory of this env's one-lane engine (not part of the reference's surface)."""
         self._engine.close()
 
     def render_mode(self) -> RenderMode:

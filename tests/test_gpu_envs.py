@@ -186,3 +186,27 @@ def test_closed_loop_example_runs_and_balances(tmp_path):
     assert m, out.stdout
     episodes, mean_return = int(m.group(1)), float(m.group(2))
     assert episodes == 0 or mean_return > 100.0, out.stdout
+
+
+def test_reference_example_loops_run_through_the_mirrors():
+    """examples/cartpole.py and examples/mountain_car.py are the caller loops of the reference's examples/cartpole.rs:7-33
+    and examples/mountain_car.rs:8-40 (incl. stepping after close(), which only drops the GUI in the reference)."""
+    import importlib.util
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(f"example_{name}", root / "examples" / f"{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    cp = load("cartpole")
+    rewards = cp.single_env(n_episodes=4, seed=1)
+    assert len(rewards) == 4 and all(8.0 <= r <= 200.0 and r == int(r) for r in rewards)  # a random policy lasts ~22 steps
+    b = cp.batched(n_envs=1 << 16, steps=100)
+    assert b["steps"] == (1 << 16) * 100 and b["finished_episodes"] > (1 << 16) * 2 and 15.0 < b["mean_return"] < 30.0
+    mc = load("mountain_car")
+    total = mc.main(seed=3, verbose=False)
+    assert 201 <= total <= 401  # the episode loop stops at done or after 201 steps; 200 more steps after close()
