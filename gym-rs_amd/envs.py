@@ -178,12 +178,22 @@ class CartPoleEnv(_SingleEnv):
             raise InvalidActionError(5, f"{action} usize invalid")
         self._engine.step_host([action])
         reward, done, _ = self._engine.get_step_result()
+        if done[0]:  # cartpole.rs:455-464: None -> Some(0) on the terminating step, then counted up (with a warning)
+            beyond = self.steps_beyond_terminated
+            object.__setattr__(self, "_steps_beyond", 0 if beyond is None else beyond + 1)
         # truncated is hard-coded false, info is Some(()) (cartpole.rs:480-481)
         return ActionReward(self.state, float(reward[0]), bool(done[0]), False, ())
+
+    @property
+    def steps_beyond_terminated(self) -> Optional[int]:
+        """The pub field of cartpole.rs:83 (``Option<usize>``): None until the episode terminated, then the number of
+        steps taken after that.  The device keeps ``is_some()`` (that is all ``step`` reads); the count is kept here."""
+        return getattr(self, "_steps_beyond", None)
 
     def reset(self, seed: Optional[int] = None, return_info: bool = False, options: Optional[BoxR] = None):
         """``Env::reset`` (cartpole.rs:485-516)."""
         self._engine.reset(seed, self._options(options))
+        object.__setattr__(self, "_steps_beyond", None)  # cartpole.rs:504
         return self.state, (() if return_info else None)
 
 

@@ -19,14 +19,19 @@ def test_assigning_a_pub_field_keeps_the_episode_single_env(gymrs):
     env = gymrs.CartPoleEnv()
     env.reset(seed=3)
     env.state = gymrs.CartPoleObservation(2.39, 3.0, 0.0, 0.0)
+    assert env.steps_beyond_terminated is None
     r1 = env.step(1)
     assert r1.done and r1.reward == 1.0  # the terminating step pays 1.0 and sets steps_beyond_terminated = Some(0)
+    assert env.steps_beyond_terminated == 0
     tick_before = env.rand_random()
     state_before = env.state
     env.gravity = 19.6  # a pub field of the reference struct
     assert env.gravity == 19.6 and env.state == state_before and env.rand_random() == tick_before
     r2 = env.step(1)
     assert r2.done and r2.reward == 0.0, "steps_beyond_terminated was lost by the assignment"
+    assert env.steps_beyond_terminated == 1
+    env.reset(seed=4)
+    assert env.steps_beyond_terminated is None
     # and the new constant is the one the next step used: compare with a fresh env given the same state
     ref = gymrs.CartPoleEnv()
     ref.gravity = 19.6
