@@ -168,11 +168,21 @@ impl Env for CartPoleEnv {
         let (rng, seed_no) = rand_random(seed);
         self.rand_random = rng;
         self.sync_down();
-        let bounds: Option<Vec<f32>> = options.map(|b| {
+        let bounds: Option<Vec<f64>> = options.map(|b| {
             let (low, high): (Vec<f64>, Vec<f64>) = (b.low.into(), b.high.into());
-            low.iter().chain(high.iter()).map(|v| *v as f32).collect()
+            low.into_iter().chain(high).collect()
         });
-        self.engine.reset(Some(seed_no), bounds.as_deref());
+        if cfg!(feature = "pcg64-reset") {
+            // the state gym-rs itself returns for this seed (its Pcg64 + Uniform chain on the device), rounded to f32
+            self.engine.reset_pcg64(Some(seed_no), bounds.as_deref());
+            // ... and `rand_random()` hands out the generator where the reference's stands after its four draws (cartpole.rs:317-324)
+            for _ in 0..4 {
+                rand::RngCore::next_u64(&mut self.rand_random);
+            }
+        } else {
+            let narrow: Option<Vec<f32>> = bounds.map(|b| b.iter().map(|v| *v as f32).collect());
+            self.engine.reset(Some(seed_no), narrow.as_deref());
+        }
         self.state = observation(&self.engine.state(0, 1));
         self.steps_beyond_terminated = None;
         (self.state, if return_info { Some(()) } else { None })

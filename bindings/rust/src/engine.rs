@@ -148,6 +148,27 @@ impl Engine {
         used
     }
 
+    /// The same reset drawn from the reference's own generator chain (`Pcg64::seed_from_u64` + `Uniform` over f64,
+    /// seeding.rs:21-26): lane i holds, rounded once to f32, what gym-rs' `reset(Some(seed + offset + i))` returns.
+    /// CartPole / MountainCar only.
+    pub fn reset_pcg64(&mut self, seed: Option<u64>, bounds_low_high: Option<&[f64]>) -> u64 {
+        if let Some(b) = bounds_low_high {
+            assert_eq!(b.len(), 2 * self.kind.state_dim(), "bounds = state_dim lows then state_dim highs");
+        }
+        let mut used = 0u64;
+        check(unsafe {
+            ffi::gymrs_reset_pcg64(
+                self.raw,
+                seed.is_some() as c_int,
+                seed.unwrap_or(0),
+                std::ptr::null(),
+                bounds_low_high.map_or(std::ptr::null(), |b| b.as_ptr()),
+                &mut used,
+            )
+        });
+        used
+    }
+
     /// One `Env::step` of every lane with host actions (one u8 per lane), then wait for it.
     pub fn step_host(&mut self, actions: &[u8]) {
         assert_eq!(actions.len() as u64, self.n);

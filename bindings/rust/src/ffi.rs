@@ -79,6 +79,14 @@ extern "C" {
     pub fn gymrs_engine_destroy(e: *mut GymrsEngine) -> c_int;
     pub fn gymrs_engine_clone(src: *mut GymrsEngine, out: *mut *mut GymrsEngine) -> c_int;
     pub fn gymrs_reset(e: *mut GymrsEngine, has_seed: c_int, seed: u64, bounds_low_high: *const f32, seed_used: *mut u64) -> c_int;
+    pub fn gymrs_reset_pcg64(
+        e: *mut GymrsEngine,
+        has_seed: c_int,
+        seed: u64,
+        seeds_dev: *const u64,
+        bounds_low_high: *const f64,
+        seed_used: *mut u64,
+    ) -> c_int;
     pub fn gymrs_step(e: *mut GymrsEngine, actions_dev: *const c_void) -> c_int;
     pub fn gymrs_step_host(e: *mut GymrsEngine, actions_host: *const c_void) -> c_int;
     pub fn gymrs_step_many(

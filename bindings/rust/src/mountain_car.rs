@@ -137,15 +137,20 @@ impl Env for MountainCarEnv {
         self.rand_random = rng;
         self.sync_down();
         // only the position is sampled (mountain_car.rs:464-501); the velocity bounds are carried but unused
-        let bounds: Option<[f32; 4]> = options.map(|b| {
-            [
-                b.low.position.into_inner() as f32,
-                b.low.velocity.into_inner() as f32,
-                b.high.position.into_inner() as f32,
-                b.high.velocity.into_inner() as f32,
-            ]
+        let bounds: Option<[f64; 4]> = options.map(|b| {
+            [b.low.position.into_inner(), b.low.velocity.into_inner(), b.high.position.into_inner(), b.high.velocity.into_inner()]
         });
-        self.engine.reset(Some(seed_no), bounds.as_ref().map(|b| &b[..]));
+        if cfg!(feature = "pcg64-reset") {
+            // the position gym-rs itself draws for this seed (its Pcg64 + Uniform chain on the device), rounded to f32
+            self.engine.reset_pcg64(Some(seed_no), bounds.as_ref().map(|b| &b[..]));
+            // ... and `rand_random()` hands out the generator where the reference's stands after its one draw (mountain_car.rs:145)
+            for _ in 0..1 {
+                rand::RngCore::next_u64(&mut self.rand_random);
+            }
+        } else {
+            let narrow: Option<[f32; 4]> = bounds.map(|b| [b[0] as f32, b[1] as f32, b[2] as f32, b[3] as f32]);
+            self.engine.reset(Some(seed_no), narrow.as_ref().map(|b| &b[..]));
+        }
         self.state = observation(&self.engine.state(0, 1));
         (self.state, if return_info { Some(()) } else { None })
     }

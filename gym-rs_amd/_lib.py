@@ -28,6 +28,7 @@ SIGNATURES = {
     "gymrs_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gymrs_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "gymrs_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, f32p, u64p]),
+    "gymrs_reset_pcg64": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), u64p]),
     "gymrs_step": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gymrs_step_host": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gymrs_step_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),

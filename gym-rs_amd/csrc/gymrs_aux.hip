@@ -2,6 +2,7 @@
 // stream, the statistics read-out, and two one-thread helpers.  Kept in their own translation unit so that the
 // step-kernel tables (gymrs_step_<env>.hip) are not rebuilt when one of these changes.
 #include "gymrs_tile.h"
+#include "gymrs_pcg64.h"
 
 namespace gymrs {
 
@@ -12,9 +13,16 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const ResetArgs a)
 {
     const uint64_t lane = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (lane >= a.n) return;
-    const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
     float ns[Env::kState];
-    Env::sample(r, a.box, ns);
+    if (a.pcg64) { // wave-uniform: the reference's own generator, one per lane (gymrs_pcg64.h)
+        Pcg64Lane g = Pcg64Lane::seed_from_u64(a.pcg_seeds ? a.pcg_seeds[lane] : a.seed + a.gid0 + lane);
+#pragma unroll
+        for (int j = 0; j < Env::kState; ++j)
+            ns[j] = j < Env::kSampled ? (float)pcg64_uniform(g, a.pcg_low[j], a.pcg_scale[j]) : 0.0f;
+    } else {
+        const u32x4 r = draw4(a.seed, a.gid0 + lane, a.tick, kStreamReset);
+        Env::sample(r, a.box, ns);
+    }
 #pragma unroll
     for (int j = 0; j < Env::kState; ++j) a.s[j][lane] = ns[j];
     if (Env::kHasObsExtra) {

@@ -603,6 +603,68 @@ gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_
 }
 
 // ---------------------------------------------------------------------------------------------
+// The default sampling box of `sample_between` in f64 (cartpole.rs:353-360: +-0.05 in every component;
+// mountain_car.rs:175-186: position in [-0.6, -0.4)).
+static double default_reset_low_f64(gymrs_env_kind kind, int) { return kind == GYMRS_CARTPOLE ? -0.05 : -0.6; }
+static double default_reset_high_f64(gymrs_env_kind kind, int) { return kind == GYMRS_CARTPOLE ? 0.05 : -0.4; }
+
+// What both reset entry points share once the seed and the sampling box are known: `pcg` = NULL draws from the Philox
+// reset stream, otherwise from one reference-style PCG64 per lane (gymrs_pcg64.h).
+struct PcgReset {
+    const uint64_t* seeds_dev;
+    double low[4], scale[4];
+};
+
+static gymrs_status reset_lanes(gymrs_engine* e, uint64_t seed, const float* lo, const float* hi, const PcgReset* pcg)
+{
+    std::memcpy(e->lo, lo, sizeof(e->lo));
+    std::memcpy(e->hi, hi, sizeof(e->hi));
+    if (gymrs_status st = fold_reset_log(e)) return st; // leaves the ring all zero; reset_kernel rewrites ep_start below
+    // seeding.rs:21-26: the generator is re-created on every reset (SURVEY Q5)
+    e->seed = seed;
+    e->tick = 0;
+    if (e->graph_exec) { // the reset box and the seed are baked into a captured graph
+        (void)hipGraphExecDestroy(e->graph_exec);
+        e->graph_exec = nullptr;
+    }
+
+    ResetArgs a;
+    std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < 4; ++j) a.s[j] = e->s[j];
+    a.obs_cos = e->obs_cos;
+    a.obs_sin = e->obs_sin;
+    a.reward = e->reward;
+    a.done = e->done;
+    a.truncated = e->truncated;
+    a.beyond = e->beyond;
+    a.ep_start = e->ep_start;
+    a.n = e->n;
+    a.gid0 = e->gid0;
+    a.seed = e->seed;
+    a.tick = e->tick;
+    a.box = make_sample_box(lo, hi, e->state_dim);
+    if (pcg) {
+        a.pcg64 = 1;
+        a.pcg_seeds = pcg->seeds_dev;
+        std::memcpy(a.pcg_low, pcg->low, sizeof(a.pcg_low));
+        std::memcpy(a.pcg_scale, pcg->scale, sizeof(a.pcg_scale));
+    }
+    HIP_TRY(launch_reset(e->kind, a, e->stream));
+    e->tick += 1;
+    e->uniform_start = e->tick;
+    e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
+    // a reset discards the open episodes and starts the statistics afresh
+    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
+    HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
+    e->open_vec = 0;
+    e->trunc_held = 0; // reset_kernel cleared the flags
+    HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
+    e->clean_shape = 0;
+    HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
+    e->n_steps_total = 0;
+    return GYMRS_OK;
+}
+
 gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const float* bounds, uint64_t* seed_used)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_reset: engine is NULL");
@@ -622,47 +684,65 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
                 return fail(GYMRS_EINVAL, "gymrs_reset: bounds need finite low < high");
         }
     }
-    std::memcpy(e->lo, lo, sizeof(lo));
-    std::memcpy(e->hi, hi, sizeof(hi));
-    if (gymrs_status st = fold_reset_log(e)) return st; // leaves the ring all zero; reset_kernel rewrites ep_start below
-    // seeding.rs:21-26: the generator is re-created on every reset (SURVEY Q5)
-    e->seed = has_seed ? seed : os_entropy();
-    e->tick = 0;
-    if (e->graph_exec) { // the reset box and the seed are baked into a captured graph
-        (void)hipGraphExecDestroy(e->graph_exec);
-        e->graph_exec = nullptr;
-    }
-    if (seed_used) *seed_used = e->seed;
+    const uint64_t s = has_seed ? seed : os_entropy();
+    if (seed_used) *seed_used = s;
+    return reset_lanes(e, s, lo, hi, nullptr);
+}
 
-    ResetArgs a;
-    std::memset(&a, 0, sizeof(a));
-    for (int j = 0; j < 4; ++j) a.s[j] = e->s[j];
-    a.obs_cos = e->obs_cos;
-    a.obs_sin = e->obs_sin;
-    a.reward = e->reward;
-    a.done = e->done;
-    a.truncated = e->truncated;
-    a.beyond = e->beyond;
-    a.ep_start = e->ep_start;
-    a.n = e->n;
-    a.gid0 = e->gid0;
-    a.seed = e->seed;
-    a.tick = e->tick;
-    a.box = make_sample_box(lo, hi, e->state_dim);
-    HIP_TRY(launch_reset(e->kind, a, e->stream));
-    e->tick += 1;
-    e->uniform_start = e->tick;
-    e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
-    // a reset discards the open episodes and starts the statistics afresh
-    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
-    HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
-    e->open_vec = 0;
-    e->trunc_held = 0; // reset_kernel cleared the flags
-    HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
-    e->clean_shape = 0;
-    HIP_TRY(launch_stats(stats_args(e), 2, e->stream));
-    e->n_steps_total = 0;
-    return GYMRS_OK;
+// rand 0.8 `UniformFloat::<f64>::new(low, high)` [RECALLED, SURVEY App. B.2]: scale = high - low, then one ulp less for
+// as long as the largest draw (1 - 2^-52) * scale + low would reach `high`.
+static bool uniform_f64_scale(double low, double high, double* scale_out)
+{
+    if (!(low < high) || !std::isfinite(low) || !std::isfinite(high)) return false;
+    double scale = high - low;
+    if (!std::isfinite(scale)) return false; // "Uniform::new: range overflow"
+    const double max_rand = 1.0 - 0x1p-52;
+    // The loop takes ~ulp(high) / (2 ulp(scale)) rounds, so a box that is very narrow for where it lies (say
+    // [1e5, 1e5 + 1e-10)) keeps the reference busy for 1e15 iterations; such boxes are refused after 2^22 rounds.
+    for (long rounds = 0;; ++rounds) {
+        volatile double product = scale * max_rand; // rounded on its own, as in the reference (no fma)
+        if (!(product + low >= high)) break;
+        if (rounds == (1L << 22)) return false;
+        uint64_t bits;
+        std::memcpy(&bits, &scale, sizeof(bits));
+        bits -= 1;
+        std::memcpy(&scale, &bits, sizeof(bits));
+    }
+    *scale_out = scale;
+    return true;
+}
+
+gymrs_status gymrs_reset_pcg64(gymrs_engine* e, int has_seed, uint64_t seed, const uint64_t* seeds_dev,
+                               const double* bounds, uint64_t* seed_used)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_reset_pcg64: engine is NULL");
+    if (e->kind == GYMRS_PENDULUM)
+        return fail(GYMRS_EINVAL, "gymrs_reset_pcg64: the reference has no Pendulum, so there is no PCG64 reset stream to reproduce");
+    HIP_TRY(hipSetDevice(e->device));
+    const int d = e->state_dim;
+    const int sampled = (e->kind == GYMRS_MOUNTAIN_CAR) ? 1 : d;
+    PcgReset pcg;
+    std::memset(&pcg, 0, sizeof(pcg));
+    pcg.seeds_dev = seeds_dev;
+    float lo[4], hi[4]; // the box the Philox re-arms of GYMRS_AUTO_RESET keep using
+    std::memcpy(lo, e->dflt_lo, sizeof(lo));
+    std::memcpy(hi, e->dflt_hi, sizeof(hi));
+    for (int j = 0; j < sampled; ++j) {
+        // the f64 defaults of cartpole.rs:353-360 / mountain_car.rs:175-186, not their f32 roundings
+        double low = bounds ? bounds[j] : default_reset_low_f64(e->kind, j);
+        double high = bounds ? bounds[d + j] : default_reset_high_f64(e->kind, j);
+        if (!uniform_f64_scale(low, high, &pcg.scale[j]))
+            return fail(GYMRS_EINVAL, "gymrs_reset_pcg64: bounds need finite low < high, a finite high - low, and a width of at least ~1e-6 of |high|");
+        pcg.low[j] = low;
+        if (bounds) {
+            lo[j] = (float)low;
+            hi[j] = (float)high;
+            if (!(lo[j] < hi[j])) return fail(GYMRS_EINVAL, "gymrs_reset_pcg64: bounds collapse in f32");
+        }
+    }
+    const uint64_t s = has_seed ? seed : os_entropy();
+    if (seed_used) *seed_used = s;
+    return reset_lanes(e, s, lo, hi, &pcg);
 }
 
 // Pendulum's open-episode reward sums live in per-wavefront slots whose lane coverage depends on the lanes per

@@ -78,6 +78,11 @@ struct ResetArgs {
     uint32_t* ep_start;
     uint64_t n, gid0, seed, tick;
     SampleBox box;
+    // gymrs_reset_pcg64 (gymrs_pcg64.h): lane i draws its state from Pcg64::seed_from_u64(pcg_seeds ? pcg_seeds[i] :
+    // seed + gid0 + i) over [pcg_low, pcg_low + pcg_scale) instead of from the Philox reset stream
+    int pcg64;
+    const uint64_t* pcg_seeds;
+    double pcg_low[4], pcg_scale[4];
 };
 
 // Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4 or 8).

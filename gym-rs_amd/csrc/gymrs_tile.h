@@ -107,6 +107,7 @@ struct CartPoleT {
     using Consts = CartPoleConsts;
     using Action = uint8_t;
     static constexpr int kState = 4;
+    static constexpr int kSampled = 4; // state words reset() draws (cartpole.rs:317-324)
     static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
     static constexpr float kReward = 1.0f;
     static constexpr bool kElideConstReward = false; // measured: +1 % here (VALU-bound; the flag load costs more than 4 B per lane of stores)
@@ -141,6 +142,7 @@ struct MountainCarT {
     using Consts = MountainCarConsts;
     using Action = uint8_t;
     static constexpr int kState = 2;
+    static constexpr int kSampled = 1; // state words reset() draws (velocity is set to 0, mountain_car.rs:162-167)
     static constexpr bool kConstReward = true; // -1.0 on every step (mountain_car.rs:423)
     static constexpr float kReward = -1.0f;
     static constexpr bool kElideConstReward = true;  // measured: 4.16 -> 3.95 us per 2^20-lane step
@@ -174,6 +176,7 @@ struct PendulumT { // spec-derived, not in the reference
     using Consts = PendulumConsts;
     using Action = float;
     static constexpr int kState = 2;
+    static constexpr int kSampled = 2; // state words reset() draws (theta, theta_dot)
     static constexpr bool kConstReward = false;
     static constexpr float kReward = 0.0f; // unused
     static constexpr bool kElideConstReward = false;

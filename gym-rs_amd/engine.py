@@ -227,6 +227,23 @@ class BatchedEngine:
                                                 bounds, C.byref(used)))
         return used.value
 
+    def reset_pcg64(self, seed: Optional[int] = None, seeds_dev: Optional[int] = None,
+                    options: Optional[Sequence[float]] = None) -> int:
+        """``reset`` with the reference's own generator chain (``gymrs_reset_pcg64``): lane i gets, rounded once to f32,
+        the state the reference's ``reset(Some(s), _, options)`` returns for ``s = seed + global_env_offset + i`` or, if
+        ``seeds_dev`` (device address of n_envs u64) is given, ``s = seeds[i]``.  ``options`` = lows then highs, f64.
+        CartPole / MountainCar only.  Returns the seed number used."""
+        bounds = None
+        if options is not None:
+            arr = np.ascontiguousarray(options, dtype=np.float64)
+            if arr.size != 2 * self.state_dim:
+                raise ValueError(f"options needs {2 * self.state_dim} floats (lows then highs)")
+            bounds = arr.ctypes.data_as(C.POINTER(C.c_double))
+        used = C.c_uint64()
+        _check(self._lib, self._lib.gymrs_reset_pcg64(self._h, 0 if seed is None else 1, 0 if seed is None else int(seed) & ((1 << 64) - 1),
+                                                      C.c_void_p(seeds_dev) if seeds_dev else None, bounds, C.byref(used)))
+        return used.value
+
     # -- Env::step ---------------------------------------------------------------------------------
     def step(self, actions_dev: int) -> None:
         """Asynchronous; ``actions_dev`` is a device address of n_envs actions."""

@@ -86,9 +86,15 @@ class _SingleEnv:
     _KIND = -1
     _FIELDS: tuple = ()
 
-    def __init__(self, render_mode: RenderMode = RenderMode.NONE, *, device: int = 0):
+    def __init__(self, render_mode: RenderMode = RenderMode.NONE, *, device: int = 0, reset_rng: str = "philox"):
+        """``reset_rng``: "philox" (the build's counter-based stream, north_star) or "pcg64": ``reset(seed)`` then
+        returns, rounded to f32, the state the reference's ``reset(Some(seed))`` returns (its own
+        ``Pcg64::seed_from_u64`` + ``Uniform`` chain, ``BatchedEngine.reset_pcg64``)."""
         if render_mode is not RenderMode.NONE:
             raise NotImplementedError("rendering is out of scope for the MI355X hot path; use RenderMode.NONE")
+        if reset_rng not in ("philox", "pcg64") or (reset_rng == "pcg64" and self._KIND == PENDULUM):
+            raise ValueError("reset_rng is 'philox' or, for CartPole / MountainCar, 'pcg64'")
+        object.__setattr__(self, "_reset_rng", reset_rng)
         object.__setattr__(self, "_params", default_params(self._KIND))
         object.__setattr__(self, "_engine", BatchedEngine(self._KIND, 1, params=self._params, flags=0, device=device))
         object.__setattr__(self, "_render_mode", render_mode)
@@ -117,6 +123,12 @@ class _SingleEnv:
         if options is None:
             return None
         return list(options.low.to_vec()) + list(options.high.to_vec())
+
+    def _reset_lane(self, seed: Optional[int], options: Optional[BoxR]) -> None:
+        if self._reset_rng == "pcg64":
+            self._engine.reset_pcg64(seed, options=self._options(options))
+        else:
+            self._engine.reset(seed, self._options(options))
 
     def render(self, mode: RenderMode = RenderMode.NONE):
         """``Env::render`` (core.rs:53): with RenderMode::None nothing is drawn (renderer.rs:52-62)."""
@@ -192,7 +204,7 @@ class CartPoleEnv(_SingleEnv):
 
     def reset(self, seed: Optional[int] = None, return_info: bool = False, options: Optional[BoxR] = None):
         """``Env::reset`` (cartpole.rs:485-516)."""
-        self._engine.reset(seed, self._options(options))
+        self._reset_lane(seed, options)
         object.__setattr__(self, "_steps_beyond", None)  # cartpole.rs:504
         return self.state, (() if return_info else None)
 
@@ -232,7 +244,7 @@ class MountainCarEnv(_SingleEnv):
 
     def reset(self, seed: Optional[int] = None, return_info: bool = False, options: Optional[BoxR] = None):
         """``Env::reset`` (mountain_car.rs:464-501)."""
-        self._engine.reset(seed, self._options(options))
+        self._reset_lane(seed, options)
         return self.state, (() if return_info else None)
 
 

@@ -138,6 +138,19 @@ gymrs_status gymrs_get_stream(gymrs_engine* e, void** hip_stream);
  * (seeding.rs:21-26). */
 gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const float* bounds_low_high,
                          uint64_t* seed_used);
+/* Optional: the same reset, but every lane draws its state from the REFERENCE's own generator chain instead of the
+ * Philox reset stream: `Pcg64::seed_from_u64(s)` (seeding.rs:21-26) and `Uniform::new(low, high).sample(rng)` over
+ * f64 (cartpole.rs:293-297,317-324,352-364; mountain_car.rs:145,162-167,175-190), so that lane i holds, rounded once
+ * to f32, the state the reference's `reset(Some(s), _, options)` returns for
+ *     s = seeds_dev[i]                       (n_envs seed numbers on the device), or, with seeds_dev = NULL,
+ *     s = seed + global_env_offset + i       (wrapping; a one-lane engine at offset 0 is the reference env itself).
+ * bounds_low_high = obs_dim lows then obs_dim highs in f64 (the reference's BoxR is f64), or NULL for the defaults.
+ * CartPole and MountainCar only (the reference has no Pendulum): GYMRS_EINVAL otherwise.  Everything else -- cleared
+ * flags, statistics, the seed echo, the Philox key of later GYMRS_AUTO_RESET re-arms -- is as for gymrs_reset.
+ * The third-party algorithms (rand 0.8, rand_pcg 0.3, rand_core 0.6) are restated from their publications and pinned
+ * by rand_pcg's own known answers (tests/golden/pcg64.json); SURVEY App. B.2. */
+gymrs_status gymrs_reset_pcg64(gymrs_engine* e, int has_seed, uint64_t seed, const uint64_t* seeds_dev,
+                               const double* bounds_low_high, uint64_t* seed_used);
 
 /* ---- Env::step(action) (core.rs:42) --------------------------------------------------------- */
 /* actions_dev: n_envs actions on the device: uint8_t for CartPole {0,1} / MountainCar {0,1,2},

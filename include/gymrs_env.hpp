@@ -59,6 +59,10 @@ struct ActionReward { // core.rs:94-106
 };
 struct Unit {}; // Rust's ()
 
+// Which generator reset() draws the start state from: the build's counter-based Philox stream (default), or the
+// reference's own Pcg64::seed_from_u64 + Uniform chain, so that reset(Some(s)) returns the reference's state for s.
+enum class ResetRng { Philox, Pcg64 };
+
 struct CartPoleObservation { // cartpole.rs:328-334; Into<Vec<f64>> order :336-349
     double x, x_dot, theta, theta_dot;
     std::vector<double> to_vec() const { return {x, x_dot, theta, theta_dot}; }
@@ -94,6 +98,15 @@ public:
     {
         std::uint64_t used = 0;
         check(gymrs_reset(e_, seed.has_value(), seed.value_or(0), bounds_low_high, &used));
+        return used;
+    }
+    // The same reset drawn from the reference's own generator chain (Pcg64::seed_from_u64 + Uniform over f64,
+    // seeding.rs:21-26): lane i = the reference's reset(Some(seed + offset + i)) rounded to f32 (gymrs_reset_pcg64).
+    std::uint64_t reset_pcg64(std::optional<std::uint64_t> seed, const double* bounds_low_high = nullptr,
+                              const std::uint64_t* seeds_dev = nullptr)
+    {
+        std::uint64_t used = 0;
+        check(gymrs_reset_pcg64(e_, seed.has_value(), seed.value_or(0), seeds_dev, bounds_low_high, &used));
         return used;
     }
     void step_device(const void* actions_dev) { check(gymrs_step(e_, actions_dev)); } // async
@@ -174,6 +187,7 @@ public:
     using Action = std::size_t;
     using Observation = CartPoleObservation;
     explicit CartPoleEnv(RenderMode mode = RenderMode::None) : env_(make(mode)) {}
+    ResetRng reset_rng = ResetRng::Philox;
 
     ActionReward<Observation, Unit> step(Action action) // Env::step, cartpole.rs:398-483
     {
@@ -189,14 +203,18 @@ public:
                                                        std::optional<BoxR<Observation>> options) // :485-516
     {
         float b[8];
+        double b64[8];
         if (options) {
             const auto lo = options->low.to_vec(), hi = options->high.to_vec();
             for (int j = 0; j < 4; ++j) {
-                b[j] = static_cast<float>(lo[j]);
-                b[4 + j] = static_cast<float>(hi[j]);
+                b[j] = static_cast<float>(b64[j] = lo[j]);
+                b[4 + j] = static_cast<float>(b64[4 + j] = hi[j]);
             }
         }
-        env_.reset(seed, options ? b : nullptr);
+        if (reset_rng == ResetRng::Pcg64)
+            env_.reset_pcg64(seed, options ? b64 : nullptr);
+        else
+            env_.reset(seed, options ? b : nullptr);
         return {state(), return_info ? std::optional<Unit>(Unit{}) : std::nullopt};
     }
     void render(RenderMode) {} // renderer.rs:52-62: nothing is drawn under RenderMode::None
@@ -246,6 +264,7 @@ public:
     using Action = std::size_t;
     using Observation = MountainCarObservation;
     explicit MountainCarEnv(RenderMode mode = RenderMode::None) : env_(make(mode)) {}
+    ResetRng reset_rng = ResetRng::Philox;
 
     ActionReward<Observation, Unit> step(Action action) // mountain_car.rs:398-435
     {
@@ -261,13 +280,17 @@ public:
                                                        std::optional<BoxR<Observation>> options) // :464-501
     {
         float b[4];
+        double b64[4];
         if (options) {
-            b[0] = (float)options->low.position;
-            b[1] = (float)options->low.velocity;
-            b[2] = (float)options->high.position;
-            b[3] = (float)options->high.velocity;
+            b[0] = (float)(b64[0] = options->low.position);
+            b[1] = (float)(b64[1] = options->low.velocity);
+            b[2] = (float)(b64[2] = options->high.position);
+            b[3] = (float)(b64[3] = options->high.velocity);
         }
-        env_.reset(seed, options ? b : nullptr);
+        if (reset_rng == ResetRng::Pcg64)
+            env_.reset_pcg64(seed, options ? b64 : nullptr);
+        else
+            env_.reset(seed, options ? b : nullptr);
         return {state(), return_info ? std::optional<Unit>(Unit{}) : std::nullopt};
     }
     void render(RenderMode) {}

@@ -51,6 +51,11 @@ class PendulumEnv(C.Structure):
     _fields_ = [("theta", C.c_double), ("theta_dot", C.c_double)]
 
 
+class Pcg64(C.Structure):
+    """rand_pcg::Pcg64 (Lcg128Xsl64): 128-bit state and increment as two u64 each."""
+    _fields_ = [("state_lo", C.c_uint64), ("state_hi", C.c_uint64), ("incr_lo", C.c_uint64), ("incr_hi", C.c_uint64)]
+
+
 class StepResult(C.Structure):
     _fields_ = [("obs", C.c_double * 4), ("reward", C.c_double), ("done", C.c_int), ("truncated", C.c_int)]
 
@@ -90,6 +95,16 @@ class Oracle:
         L.orc_cartpole_reset_batch.argtypes = [C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, _f64, _f64, _f64, _f64]
         L.orc_mountain_car_reset_batch.argtypes = [C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, _f64, _f64]
         L.orc_pendulum_reset_batch.argtypes = [C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, _f64, _f64]
+        L.orc_pcg64_new.argtypes = [C.POINTER(Pcg64)] + [C.c_uint64] * 4
+        L.orc_pcg64_from_seed.argtypes = [C.POINTER(Pcg64), C.c_char_p]
+        L.orc_pcg64_seed_from_u64.argtypes = [C.POINTER(Pcg64), C.c_uint64]
+        L.orc_pcg64_next_u64.restype = C.c_uint64
+        L.orc_pcg64_next_u64.argtypes = [C.POINTER(Pcg64)]
+        L.orc_uniform_f64_new.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_double)]
+        L.orc_uniform_f64_sample.restype = C.c_double
+        L.orc_uniform_f64_sample.argtypes = [C.POINTER(Pcg64), C.c_double, C.c_double]
+        L.orc_cartpole_reset_pcg64.argtypes = [C.POINTER(CartPoleEnv), C.c_uint64, C.c_void_p]
+        L.orc_mountain_car_reset_pcg64.argtypes = [C.POINTER(MountainCarEnv), C.c_uint64, C.c_void_p]
         L.orc_baseline_loop.restype = C.c_double
         L.orc_baseline_loop.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]
 
@@ -123,6 +138,40 @@ class Oracle:
             return None, None
         arr = np.ascontiguousarray(b, dtype=np.float64)
         return arr, arr.ctypes.data_as(C.c_void_p)
+
+    # -- the reference's own reset stream (Pcg64::seed_from_u64 + Uniform<f64>) --
+    def pcg64(self, *, new=None, from_seed=None, seed_from_u64=None) -> Pcg64:
+        g = Pcg64()
+        if new is not None:
+            state, stream = new
+            m = (1 << 64) - 1
+            self.lib.orc_pcg64_new(C.byref(g), state & m, state >> 64, stream & m, stream >> 64)
+        elif from_seed is not None:
+            assert len(from_seed) == 32
+            self.lib.orc_pcg64_from_seed(C.byref(g), bytes(from_seed))
+        else:
+            self.lib.orc_pcg64_seed_from_u64(C.byref(g), int(seed_from_u64))
+        return g
+
+    def pcg64_next(self, g: Pcg64) -> int:
+        return int(self.lib.orc_pcg64_next_u64(C.byref(g)))
+
+    def uniform_f64_scale(self, low: float, high: float):
+        """UniformFloat<f64>::new(low, high).scale, or None where the reference panics."""
+        out = C.c_double()
+        return None if self.lib.orc_uniform_f64_new(low, high, C.byref(out)) else out.value
+
+    def reset_pcg64(self, kind: int, seed: int, bounds=None):
+        """The f64 state ``reset(Some(seed), _, bounds)`` of the reference returns (kind 0 CartPole, 1 MountainCar);
+        None where it would panic."""
+        keep, ptr = self._bounds(bounds)
+        if kind == 0:
+            e = CartPoleEnv()
+            rc = self.lib.orc_cartpole_reset_pcg64(C.byref(e), seed & ((1 << 64) - 1), ptr)
+            return None if rc else [e.x, e.x_dot, e.theta, e.theta_dot]
+        e = MountainCarEnv()
+        rc = self.lib.orc_mountain_car_reset_pcg64(C.byref(e), seed & ((1 << 64) - 1), ptr)
+        return None if rc else [e.position, e.velocity]
 
     # -- scalar envs --
     def cartpole_step(self, env: CartPoleEnv, action: int, params=None):

@@ -217,6 +217,143 @@ void orc_cartpole_reset(orc_cartpole_env *e, uint64_t seed, uint64_t gid, uint64
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* The reference's OWN reset stream (seeding.rs:21-26 -> rand_pcg::Pcg64, rand::distributions::Uniform).
+ * Third-party crates absent from /root/reference (Cargo.toml:24-33: rand 0.8, rand_pcg 0.3; rand_core 0.6 through
+ * them; Cargo.lock is git-ignored, so the patch versions are unpinned).  Their published algorithms, restated
+ * [RECALLED, SURVEY App. B.2], pinned by rand_pcg's own test values (tests/golden/pcg64.json) and cross-checked
+ * against numpy.random.PCG64 (the same LCG multiplier and XSL-RR output) in tests/test_pcg64_reset.py; the uniform
+ * stage is pinned only once bindings/rust/src/bin/make_golden.rs has written from_reference/reset_kat.json.  */
+typedef unsigned __int128 u128;
+#define PCG_MUL ((((u128)0x2360ED051FC65DA4ull) << 64) | (u128)0x4385DF649FCCF645ull)
+
+static void pcg64_step(orc_pcg64 *g)
+{
+    u128 st = ((u128)g->state_hi << 64) | g->state_lo;
+    const u128 inc = ((u128)g->incr_hi << 64) | g->incr_lo;
+    st = st * PCG_MUL + inc;
+    g->state_lo = (uint64_t)st;
+    g->state_hi = (uint64_t)(st >> 64);
+}
+
+/* rand_pcg 0.3 Lcg128Xsl64::from_state_incr: "move away from the initial value" */
+static void pcg64_from_state_incr(orc_pcg64 *g, u128 state, u128 incr)
+{
+    state += incr;
+    g->state_lo = (uint64_t)state;
+    g->state_hi = (uint64_t)(state >> 64);
+    g->incr_lo = (uint64_t)incr;
+    g->incr_hi = (uint64_t)(incr >> 64);
+    pcg64_step(g);
+}
+
+/* Lcg128Xsl64::new(state, stream): increment = (stream << 1) | 1 */
+void orc_pcg64_new(orc_pcg64 *g, uint64_t state_lo, uint64_t state_hi, uint64_t stream_lo, uint64_t stream_hi)
+{
+    const u128 stream = ((u128)stream_hi << 64) | stream_lo;
+    pcg64_from_state_incr(g, ((u128)state_hi << 64) | state_lo, (stream << 1) | 1);
+}
+
+/* Lcg128Xsl64::from_seed: four little-endian u64; state = words 0,1; increment = words 2,3 with bit 0 forced */
+void orc_pcg64_from_seed(orc_pcg64 *g, const uint8_t seed[32])
+{
+    uint64_t w[4];
+    for (int i = 0; i < 4; ++i) {
+        w[i] = 0;
+        for (int b = 7; b >= 0; --b) w[i] = (w[i] << 8) | seed[8 * i + b];
+    }
+    pcg64_from_state_incr(g, ((u128)w[1] << 64) | w[0], (((u128)w[3] << 64) | w[2]) | 1);
+}
+
+/* rand_core 0.6 SeedableRng::seed_from_u64: a PCG32 (XSH-RR) fills the seed 4 bytes at a time */
+void orc_pcg64_seed_from_u64(orc_pcg64 *g, uint64_t state)
+{
+    uint8_t seed[32];
+    for (int chunk = 0; chunk < 8; ++chunk) {
+        state = state * 6364136223846793005ull + 11634580027462260723ull;
+        const uint32_t xorshifted = (uint32_t)(((state >> 18) ^ state) >> 27);
+        const uint32_t rot = (uint32_t)(state >> 59);
+        const uint32_t x = (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+        for (int b = 0; b < 4; ++b) seed[4 * chunk + b] = (uint8_t)(x >> (8 * b));
+    }
+    orc_pcg64_from_seed(g, seed);
+}
+
+/* next_u64: step, then XSL-RR 128/64 */
+uint64_t orc_pcg64_next_u64(orc_pcg64 *g)
+{
+    pcg64_step(g);
+    const uint32_t rot = (uint32_t)(g->state_hi >> 58);
+    const uint64_t xsl = g->state_hi ^ g->state_lo;
+    return (xsl >> rot) | (xsl << ((64 - rot) & 63));
+}
+
+/* rand 0.8 UniformFloat<f64>::new(low, high) -> scale; returns -1 where the reference panics */
+int orc_uniform_f64_new(double low, double high, double *scale_out)
+{
+    if (!(low < high)) return -1;                  /* "Uniform::new called with `low >= high`" */
+    if (!isfinite(low) || !isfinite(high)) return -1; /* "... non-finite boundaries" */
+    const double max_rand = 1.0 - 0x1p-52;          /* (u64::MAX >> 12) as a double in [1,2), minus 1 */
+    double scale = high - low;
+    if (!isfinite(scale)) return -1;                /* "Uniform::new: range overflow" */
+    /* NOTE: the loop takes ~ulp(high) / (2 ulp(scale)) rounds: bounds like [1e5, 1e5 + 1e-10) keep the reference
+     * busy for 1e15 iterations.  The oracle gives up after 2^22 rounds (-2: "the reference would hang"). */
+    for (long rounds = 0; scale * max_rand + low >= high; ++rounds) {
+        if (rounds == (1L << 22)) return -2;
+        uint64_t bits;
+        memcpy(&bits, &scale, 8);
+        bits -= 1;                                  /* decrease_masked: one ulp down */
+        memcpy(&scale, &bits, 8);
+    }
+    *scale_out = scale;
+    return 0;
+}
+
+/* UniformFloat<f64>::sample: 52 bits into [1,2), minus 1, times scale, plus low */
+double orc_uniform_f64_sample(orc_pcg64 *g, double low, double scale)
+{
+    const uint64_t bits = (orc_pcg64_next_u64(g) >> 12) | 0x3FF0000000000000ull;
+    double value1_2;
+    memcpy(&value1_2, &bits, 8);
+    const double value0_1 = value1_2 - 1.0;
+    return value0_1 * scale + low;
+}
+
+/* cartpole.rs:485-516 with seed = Some(seed): Pcg64::seed_from_u64, then x, x_dot, theta, theta_dot in that order
+ * (cartpole.rs:317-324) from four samplers built BEFORE the first draw (cartpole.rs:293-297). */
+int orc_cartpole_reset_pcg64(orc_cartpole_env *e, uint64_t seed, const double *b)
+{
+    static const double dflt[8] = {-0.05, -0.05, -0.05, -0.05, 0.05, 0.05, 0.05, 0.05};
+    if (!b) b = dflt;
+    double scale[4], v[4];
+    for (int j = 0; j < 4; ++j)
+        if (orc_uniform_f64_new(b[j], b[4 + j], &scale[j])) return -1;
+    orc_pcg64 g;
+    orc_pcg64_seed_from_u64(&g, seed);
+    for (int j = 0; j < 4; ++j) v[j] = orc_uniform_f64_sample(&g, b[j], scale[j]);
+    e->x = v[0];
+    e->x_dot = v[1];
+    e->theta = v[2];
+    e->theta_dot = v[3];
+    e->has_steps_beyond = 0; /* cartpole.rs:504 */
+    e->steps_beyond = 0;
+    return 0;
+}
+
+/* mountain_car.rs:464-501: one draw for the position (:145), velocity = 0 (:162-167); bounds {low pos, low vel, high pos, high vel} */
+int orc_mountain_car_reset_pcg64(orc_mountain_car_env *e, uint64_t seed, const double *b)
+{
+    static const double dflt[4] = {-0.6, 0.0, -0.4, 0.0};
+    if (!b) b = dflt;
+    double scale;
+    if (orc_uniform_f64_new(b[0], b[2], &scale)) return -1;
+    orc_pcg64 g;
+    orc_pcg64_seed_from_u64(&g, seed);
+    e->position = orc_uniform_f64_sample(&g, b[0], scale);
+    e->velocity = 0.0;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* MountainCar                                                                           */
 
 void orc_mountain_car_default_params(orc_mountain_car_params *p)

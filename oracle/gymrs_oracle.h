@@ -85,6 +85,19 @@ int orc_cartpole_step(orc_cartpole_env *e, const orc_cartpole_params *p, size_t 
 void orc_cartpole_reset(orc_cartpole_env *e, uint64_t seed, uint64_t gid, uint64_t tick,
                         const double *bounds_low_high);
 
+/* ---- the reference's own reset stream: Pcg64::seed_from_u64 + Uniform<f64> (seeding.rs:21-26) ---- */
+typedef struct {
+    uint64_t state_lo, state_hi, incr_lo, incr_hi;
+} orc_pcg64;
+void orc_pcg64_new(orc_pcg64 *g, uint64_t state_lo, uint64_t state_hi, uint64_t stream_lo, uint64_t stream_hi);
+void orc_pcg64_from_seed(orc_pcg64 *g, const uint8_t seed[32]);
+void orc_pcg64_seed_from_u64(orc_pcg64 *g, uint64_t seed);
+uint64_t orc_pcg64_next_u64(orc_pcg64 *g);
+int orc_uniform_f64_new(double low, double high, double *scale_out); /* -1 where Uniform::new panics */
+double orc_uniform_f64_sample(orc_pcg64 *g, double low, double scale);
+/* reset(Some(seed), _, bounds) of the reference in f64; bounds = lows then highs, or NULL; -1 where it would panic */
+int orc_cartpole_reset_pcg64(orc_cartpole_env *e, uint64_t seed, const double *bounds_low_high);
+
 /* ---- MountainCar ------------------------------------------------------------------ */
 typedef struct {
     double min_position, max_position, max_speed, goal_position, goal_velocity; /* mountain_car.rs:344-348 */
@@ -100,6 +113,7 @@ int orc_mountain_car_step(orc_mountain_car_env *e, const orc_mountain_car_params
                           orc_step_result *out);
 void orc_mountain_car_reset(orc_mountain_car_env *e, uint64_t seed, uint64_t gid, uint64_t tick,
                             const double *bounds_low_high /* {low_pos, high_pos} or NULL */);
+int orc_mountain_car_reset_pcg64(orc_mountain_car_env *e, uint64_t seed, const double *bounds_low_high);
 
 /* ---- Pendulum (spec-derived; NOT in the reference; parity unpinned) ---------------- */
 typedef struct {

@@ -24,6 +24,12 @@ def pytest_collection_modifyitems(config, items):
     except Exception:
         has_gpu = False
     if has_gpu:
+        # a test stuck inside a native call (a kernel that never ends, a host loop) must fail, not sit on the GPU box until
+        # the runner's own limit: pytest-timeout's thread method dumps the stacks and exits even from inside ctypes
+        if config.pluginmanager.hasplugin("timeout"):
+            for item in items:
+                if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                    item.add_marker(pytest.mark.timeout(600, method="thread"))
         return
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:

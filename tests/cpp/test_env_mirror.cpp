@@ -80,12 +80,23 @@ int main()
         // options override the sampling box
         auto [o3, i3] = env.reset(1, false, BoxR<CartPoleObservation>{{1., 2., 0.1, 5.}, {1.5, 3., 0.2, 6.}});
         REQUIRE(o3.x >= 1. && o3.x < 1.5 && o3.x_dot >= 2. && o3.theta >= 0.0999 && o3.theta_dot >= 5. && o3.theta_dot < 6.);
+        // the reference's own reset stream: Pcg64::seed_from_u64(42) + four Uniform draws (oracle/gymrs_oracle.c,
+        // orc_cartpole_reset_pcg64; tests/test_pcg64_reset.py pins the chain), rounded once to f32
+        env.reset_rng = ResetRng::Pcg64;
+        auto [o4, i4] = env.reset(42, false, std::nullopt);
+        REQUIRE(o4.x == (double)(float)-0.027348748207168663 && o4.x_dot == (double)(float)-0.02608933096814006);
+        REQUIRE(o4.theta == (double)(float)0.02608334106867409 && o4.theta_dot == (double)(float)0.002783965735815165);
+        REQUIRE(!env.step(0).done);
     }
     {
         MountainCarEnv env(RenderMode::None);
         REQUIRE(env.action_space() == Discrete{3});
         auto [obs, info] = env.reset(1, false, std::nullopt);
         REQUIRE(obs.position >= -0.6 - 1e-7 && obs.position < -0.4 && obs.velocity == 0.0);
+        env.reset_rng = ResetRng::Pcg64; // mountain_car.rs:464-501 with the reference's generator: one draw, velocity 0
+        auto [pc, pi] = env.reset(42, false, std::nullopt);
+        REQUIRE(pc.position == (double)(float)-0.5546974964143373 && pc.velocity == 0.0);
+        env.reset_rng = ResetRng::Philox;
         env.set_state({-0.5, 0.0});
         int t = 0;
         double total = 0;
