@@ -1,7 +1,7 @@
 //! `CartPoleEnv` with the reference's public surface (cartpole.rs:51-87, 389-560), one GPU lane behind it.
 //!
-//! The pub physics fields can be edited between steps like the reference's; the engine takes its constants
-//! at creation, so an edit is noticed on the next `step`/`reset` and the engine is rebuilt around the current state.
+//! The pub physics fields can be edited between steps like the reference's: an edit is noticed on the next
+//! `step`/`reset` and pushed down with `gymrs_set_params`, which changes nothing but the constants.
 use crate::engine::Engine;
 use crate::ffi::CartPoleParams;
 use gym_rs::core::{ActionReward, Env, EnvProperties};

@@ -12,19 +12,20 @@ REPO=$PWD
 SHA=$(python -c "import bench; print(bench.kernel_source_sha16())")
 echo "kernel_source_sha16 $SHA" > "$OUT/${TAG}_sha.txt"
 
-# 1. the bench lines: the driver's own command, the default form, the other configs
+# 1. HBM traffic (PMC FETCH_SIZE / WRITE_SIZE, one counter per pass): bench.py runs the two rocprofv3 passes itself and
+#    refreshes profiles/pmc_traffic.json (stamped with the kernel source hash), which is copied back below.
+#    FIRST, so that the bench lines of step 2 carry roofline.traffic of these very kernels
+for env in cartpole mountain_car pendulum; do
+    python bench.py --env $env --pmc-traffic --cpu-seconds 0 --no-probe > "$OUT/${TAG}_bench_pmc_${env}.json" 2> "$OUT/${TAG}_bench_pmc_${env}.err"
+done
+cp profiles/pmc_traffic.json "$OUT/${TAG}_pmc_traffic.json"
+
+# 2. the bench lines: the driver's own command, the default form, the other configs
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_form.json" 2> "$OUT/${TAG}_bench_driver_form.err"
 for env in cartpole mountain_car pendulum; do
     python bench.py --env $env > "$OUT/${TAG}_bench_${env}.json" 2> "$OUT/${TAG}_bench_${env}.err"
 done
 python bench.py --cpu-seconds 0 --no-probe --graph > "$OUT/${TAG}_bench_cartpole_graph.json" 2>/dev/null
-
-# 2. HBM traffic (PMC FETCH_SIZE / WRITE_SIZE, one counter per pass): bench.py runs the two rocprofv3 passes itself and
-#    refreshes profiles/pmc_traffic.json (stamped with the kernel source hash), which is copied back below
-for env in cartpole mountain_car pendulum; do
-    python bench.py --env $env --pmc-traffic --cpu-seconds 0 --no-probe > "$OUT/${TAG}_bench_pmc_${env}.json" 2> "$OUT/${TAG}_bench_pmc_${env}.err"
-done
-cp profiles/pmc_traffic.json "$OUT/${TAG}_pmc_traffic.json"
 
 # 3. kernel trace of the bench command, eager and as graph replays (under the tracer eager launches are host-bound)
 cd /tmp
@@ -89,6 +90,7 @@ for n in 1024 16384 131072; do
 done > "$OUT/${TAG}_small_batch_graph.jsonl"
 
 # 7. A/B against the round-1 library if it was shipped (_ab/libgymrs_r01.so): same box, same call
+python tools/exp_split_streams.py > "$OUT/${TAG}_split_streams.log" 2>&1
 if [ -f _ab/libgymrs_r01.so ]; then
     for i in 1 2 3; do
         python tools/step_timer.py --lib _ab/libgymrs_r01.so --reps 5
