@@ -149,6 +149,79 @@ __global__ __launch_bounds__(kStatsThreads) void stats_partial_kernel(const uint
     }
 }
 
+// Age of the oldest open episode (see launch_max_age).  Like the statistics read-out: two launches, no atomics (4096
+// same-address atomics, one per wavefront, made a first version take 30-80 us).  max_age_partial_kernel streams ep_start
+// with plain loads (the step kernels' scattered stores want the array in the Infinity Cache) and leaves one maximum per
+// workgroup; max_age_finalize_kernel (one workgroup) takes the maximum of those and hands it to the host through mapped
+// host memory -- no copy engine in the stream: a 4-byte device-to-host copy costs the compute queue tens of
+// microseconds of cross-engine synchronisation.  ~4 + 3 us at 2^20 lanes, a few times per time limit.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kStatsThreads) void max_age_partial_kernel(const uint32_t* __restrict__ ep_start, uint64_t n, uint32_t tick_ref,
+                                                                        uint32_t* __restrict__ partials)
+{
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    __shared__ uint32_t s_age[kStatsThreads / 64];
+    const uint64_t tid = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kStatsThreads;
+    const uint64_t n4 = n >> 2;
+    const u4* v = reinterpret_cast<const u4*>(ep_start);
+    uint32_t age = 0;
+    auto upd = [&](uint32_t start) {
+        const uint32_t a = tick_ref - start; // 32-bit ticks wrap; ages do not reach 2^32
+        age = a > age ? a : age;
+    };
+    for (uint64_t i = tid; i < n4; i += stride) {
+        const u4 x = v[i];
+        upd(x.x);
+        upd(x.y);
+        upd(x.z);
+        upd(x.w);
+    }
+    for (uint64_t i = (n4 << 2) + tid; i < n; i += stride) upd(ep_start[i]);
+    age = wave_max_u32(age);
+    if ((threadIdx.x & 63u) == 0) s_age[threadIdx.x >> 6] = age;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        age = wave_max_u32(threadIdx.x < kStatsThreads / 64 ? s_age[threadIdx.x] : 0u);
+        if (threadIdx.x == 0) partials[blockIdx.x] = age;
+    }
+}
+
+__global__ __launch_bounds__(kStatsMaxBlocks) void max_age_finalize_kernel(const uint32_t* __restrict__ partials, uint32_t n_partials,
+                                                                           volatile uint32_t* host_out2, uint32_t seq)
+{
+    __shared__ uint32_t s_age[kStatsMaxBlocks / 64];
+    uint32_t age = threadIdx.x < n_partials ? partials[threadIdx.x] : 0u;
+    age = wave_max_u32(age);
+    if ((threadIdx.x & 63u) == 0) s_age[threadIdx.x >> 6] = age;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kStatsMaxBlocks / 64; ++w) age = s_age[w] > age ? s_age[w] : age;
+        host_out2[0] = age;
+        __threadfence_system();
+        host_out2[1] = seq; // the host reads the age only after it has seen the sequence number
+        __threadfence_system();
+    }
+}
+
+hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
+                          hipStream_t stream)
+{
+    const uint64_t want = (n / 4 + kStatsThreads - 1) / kStatsThreads;
+    const uint32_t grid = (uint32_t)(want < 1 ? 1 : (want > (uint64_t)kStatsMaxBlocks ? (uint64_t)kStatsMaxBlocks : want));
+    hipLaunchKernelGGL(max_age_partial_kernel, dim3(grid), dim3(kStatsThreads), 0, stream, ep_start, n, tick_ref, partials);
+    hipLaunchKernelGGL(max_age_finalize_kernel, dim3(1), dim3(kStatsMaxBlocks), 0, stream, partials, grid, host_out2, seq);
+    return hipGetLastError();
+}
+
 // mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps}; mode 1: remember L as the new base
 // (statistics cleared); mode 2: base = 0 (after reset(); n_partials = 0).
 __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const unsigned long long* __restrict__ partials, uint32_t n_partials,

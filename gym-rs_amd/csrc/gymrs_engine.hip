@@ -5,6 +5,8 @@
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -118,6 +120,24 @@ struct gymrs_engine {
     unsigned long long* tick_dev = nullptr;
     void* comm = nullptr; // ncclComm_t
     int n_ranks = 1;
+    // GYMRS_TIME_LIMIT elision (CartPole with all three flags): a launch whose tick cannot take any lane to the limit runs
+    // the kernel WITHOUT the limit -- the reset-logged headline kernel -- and the `truncated` array stays all zero.  start_bound = a tick no open episode started before (ep_start only grows, so a
+    // stale bound stays valid); refreshed asynchronously from the age of the oldest open episode (max_age_kernel).
+    bool limit_elidable = false;
+    uint64_t start_bound = 0;
+    bool trunc_zero = false;            // the `truncated` array is known to hold zeros only
+    uint32_t* age_dev = nullptr;        // device scratch of a refresh: one maximum per workgroup
+    volatile uint32_t* age_host = nullptr; // mapped host memory the device writes {age, sequence number} into
+    uint32_t* age_host_dev = nullptr;   // the device's address of it
+    uint32_t age_seq = 0;               // sequence number of the refresh in flight
+    bool age_pending = false;
+    bool age_near_done = false;         // the one refresh of this approach to the limit has been issued
+    bool last_elided = false;           // the previous per-step launch ran without the limit
+    uint64_t age_ref_tick = 0;          // tick the ages of the refresh in flight are measured from
+    uint64_t age_next_refresh = 0;      // no new refresh before this tick (doubling back-off while the limit stays reachable)
+    uint32_t age_backoff = 8;
+    uint64_t limit_elided_launches = 0; // for the serde view's engine extras (tests, diagnostics)
+    uint64_t age_refreshes = 0, age_waits = 0, age_wait_ns = 0;
 };
 
 static RcclApi g_rccl;
@@ -224,10 +244,17 @@ static gymrs_status fold_reset_log(gymrs_engine* e)
 
 // About to launch ONE per-step kernel at the engine's current tick: *fold = it has to be the folding variant (the ring
 // would be full after it; that launch folds the whole ring inside the kernel, its own masks included).
-static gymrs_status log_before_step(gymrs_engine* e, uint32_t* fold)
+// Does a launch with these flags keep its episode bookkeeping in the reset log?  (= TileRegs<CartPoleT, ..>::LOGGED)
+static bool launch_is_logged(const gymrs_engine* e, uint32_t flags)
+{
+    return e->reset_log && (flags & GYMRS_TRACK_STATS) && (flags & GYMRS_AUTO_RESET) && !(flags & GYMRS_TIME_LIMIT);
+}
+
+static gymrs_status log_before_step(gymrs_engine* e, uint32_t flags, uint32_t* fold)
 {
     *fold = 0;
     if (!e->reset_log) return GYMRS_OK;
+    if (!launch_is_logged(e, flags)) return fold_reset_log(e); // this launch reads ep_start itself: nothing may be pending
     if (e->log_pending != 0 && e->log_vec != e->vec) { // rows are laid out per wavefront of ONE launch shape
         if (gymrs_status st = fold_reset_log(e)) return st;
     }
@@ -241,6 +268,113 @@ static gymrs_status log_before_step(gymrs_engine* e, uint32_t* fold)
     } else {
         e->log_pending += 1;
     }
+    return GYMRS_OK;
+}
+
+// ---- GYMRS_TIME_LIMIT elision (host side) -----------------------------------------------------------------------------
+static uint32_t limit_of(const gymrs_engine* e) { return e->consts.cp.max_steps; } // elidable engines are CartPole
+
+// What is known about every lane's episode clock after something rewrote ep_start wholesale (reset: all start at
+// `bound`; snapshot load: nothing, bound = 0 makes the next launches keep the limit until a refresh has come back).
+static void limit_restart(gymrs_engine* e, uint64_t bound, bool trunc_zero)
+{
+    e->start_bound = bound;
+    e->trunc_zero = trunc_zero;
+    e->age_pending = false; // a refresh still in flight measured another episode clock: its result is never adopted
+    e->age_near_done = false;
+    e->last_elided = false;
+    e->age_next_refresh = 0;
+    e->age_backoff = 8;
+}
+
+// Wait until the refresh in flight has published its result (mapped host memory; the device writes the age, then the
+// sequence number).  A caller that waits for every step finds it there; one that queues launches far ahead of the GPU
+// waits here until the GPU has caught up with the refresh.
+static gymrs_status wait_for_age(gymrs_engine* e)
+{
+    for (uint64_t spins = 0; e->age_host[1] != e->age_seq; ++spins) {
+        if ((spins & 0xfffu) == 0xfffu) { // every few microseconds: is the stream still alive?
+            const hipError_t q = hipStreamQuery(e->stream);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(GYMRS_EHIP, std::string("time-limit refresh: ") + hipGetErrorString(q));
+            if (q == hipSuccess && e->age_host[1] != e->age_seq)
+                return fail(GYMRS_EHIP, "time-limit refresh: the stream is idle but the result never arrived");
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return GYMRS_OK;
+}
+
+// The flags of ONE per-step launch at the engine's current tick.  A step takes a lane to the limit iff
+// tick + 1 - ep_start >= max_steps (advance_tile); with ep_start >= start_bound for every lane, none can while
+// tick + 1 - start_bound < max_steps.  start_bound comes from max_age_kernel, launched
+//   * once per approach, `margin` launches before the bound would expire -- under a policy whose episodes end long before
+//     the limit (random CartPole: the oldest of 2^20 open episodes is a few hundred steps old) the result moves the bound on
+//     and the limit is never checked;
+//   * while the limit IS reachable: right after the first launch that checked it (if that launch truncated the few old
+//     episodes there were, the refresh behind it says so and the launches go on without the limit), then at a doubling
+//     distance up to 256 launches (a policy that keeps lanes alive up to the limit pays one 4 MB reduction and one
+//     drained queue per 256 steps).
+static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
+{
+    uint32_t flags = launch_flags_of(e);
+    *out = flags;
+    if (!e->limit_elidable) return GYMRS_OK;
+    const uint64_t limit = limit_of(e);
+    const uint64_t margin = limit / 4 < 16 ? limit / 4 : 16;
+    auto adopt = [e]() {
+        e->age_pending = false;
+        const uint64_t bound = e->age_ref_tick - (uint64_t)e->age_host[0];
+        if (bound > e->start_bound) e->start_bound = bound;
+    };
+    if (e->age_pending && e->age_host[1] == e->age_seq) { // one load from host memory per launch, no runtime call
+        std::atomic_thread_fence(std::memory_order_acquire);
+        adopt();
+    }
+    if (e->age_pending && e->tick + 1 - e->start_bound >= limit) { // the answer decides THIS launch
+        const auto t0 = std::chrono::steady_clock::now();
+        if (gymrs_status st = wait_for_age(e)) return st;
+        e->age_waits += 1;
+        e->age_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        adopt();
+    }
+    const uint64_t oldest = e->tick + 1 - e->start_bound; // no episode is older than this after the step
+    const bool reachable = oldest >= limit, near = oldest + margin >= limit;
+    if (!near) e->age_near_done = false;
+    bool refresh = false;
+    if (!e->age_pending) {
+        if (reachable) {
+            if (e->last_elided) { // first launch that has to check the limit: look again BEHIND it
+                e->age_next_refresh = e->tick + 1;
+                e->age_backoff = 8;
+            } else if (e->tick >= e->age_next_refresh) {
+                refresh = true;
+                e->age_next_refresh = e->tick + e->age_backoff;
+                e->age_backoff = e->age_backoff < 256 ? e->age_backoff * 2 : 256;
+            }
+        } else if (near && !e->age_near_done) {
+            refresh = true;
+            e->age_near_done = true;
+        }
+    }
+    if (refresh) {
+        e->age_seq += 1;
+        HIP_TRY(launch_max_age(e->ep_start, e->n, (uint32_t)e->tick, e->age_dev, e->age_host_dev, e->age_seq, e->stream));
+        e->age_pending = true;
+        e->age_ref_tick = e->tick;
+        e->age_refreshes += 1;
+    }
+    if (!reachable) {
+        flags &= ~(uint32_t)GYMRS_TIME_LIMIT;
+        if (!e->trunc_zero) { // the last launch with the limit may have left ones behind
+            HIP_TRY(hipMemsetAsync(e->truncated, 0, (size_t)e->n, e->stream));
+            e->trunc_zero = true;
+        }
+        e->limit_elided_launches += 1;
+    } else {
+        e->trunc_zero = false;
+    }
+    e->last_elided = !reachable;
+    *out = flags;
     return GYMRS_OK;
 }
 
@@ -382,6 +516,8 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
     (void)hipFree(e->reset_log);
+    (void)hipFree(e->age_dev);
+    if (e->age_host) (void)hipHostFree(const_cast<uint32_t*>(e->age_host));
     (void)hipFree(e->wave_open);
     (void)hipFree(e->wave_clean);
     (void)hipFree(e->err);
@@ -525,10 +661,28 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     // workgroups of up to 16 waves
     e->n_stat_blocks = (uint32_t)((((n_envs + 255) / 256) + 15) / 16 * 16);
     chk(dev_alloc(&e->block_stats, (size_t)e->n_stat_blocks * 2));
-    if ((flags & GYMRS_TRACK_STATS) && !(flags & GYMRS_TIME_LIMIT) && kind == GYMRS_CARTPOLE) { // = TileRegs<CartPoleT, ..>::LOGGED
+    // with all three flags a launch drops the time limit whenever no lane can reach it (flags_for_step)
+    constexpr uint32_t kAllThree = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT;
+    // CartPole only: there the launch without the limit is the reset-logged kernel (6.5 vs 6.7-6.9 us at 2^20 lanes).  For
+    // MountainCar it would only spare the dense ep_start read, and under a random policy every lane is truncated in the
+    // same step every 200 steps: the two refreshes and two exact launches per cycle cost what the 198 others gain.
+    e->limit_elidable = kind == GYMRS_CARTPOLE && (flags & kAllThree) == kAllThree;
+    if ((flags & GYMRS_TRACK_STATS) && (flags & GYMRS_AUTO_RESET) && kind == GYMRS_CARTPOLE &&
+        (!(flags & GYMRS_TIME_LIMIT) || e->limit_elidable)) { // launches that are TileRegs<CartPoleT, ..>::LOGGED will happen
         // reset log: kResetLogRows rows of one bit per lane (2^20 lanes: 128 KiB per row)
         e->log_row_words = e->n_stat_blocks * 4;
         chk(dev_alloc(&e->reset_log, (size_t)kResetLogRows * e->log_row_words));
+    }
+    if (e->limit_elidable) {
+        chk(dev_alloc(&e->age_dev, (size_t)kStatsPartials)); // scratch of the refresh: one maximum per workgroup
+        void* host = nullptr;
+        if (st == GYMRS_OK && (hipHostMalloc(&host, 2 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                               hipHostGetDevicePointer(reinterpret_cast<void**>(&e->age_host_dev), host, 0) != hipSuccess))
+            st = fail(GYMRS_EHIP, "hipHostMalloc (age words)");
+        if (host) {
+            std::memset(host, 0, 2 * sizeof(uint32_t));
+            e->age_host = static_cast<volatile uint32_t*>(host);
+        }
     }
     chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
@@ -653,6 +807,7 @@ static gymrs_status reset_lanes(gymrs_engine* e, uint64_t seed, const float* lo,
     e->tick += 1;
     e->uniform_start = e->tick;
     e->epoch = (uint32_t)e->tick; // what reset_kernel wrote into ep_start
+    limit_restart(e, e->tick, true); // every episode starts now; reset_kernel cleared `truncated`
     // a reset discards the open episodes and starts the statistics afresh
     HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
     HIP_TRY(hipMemsetAsync(e->wave_open, 0, (size_t)e->n_stat_blocks * sizeof(double), e->stream));
@@ -773,9 +928,11 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     if (!e || !actions_dev) return fail(GYMRS_EINVAL, "gymrs_step: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     if (gymrs_status st = prepare_open_sums(e, e->vec)) return st;
+    uint32_t flags = 0;
+    if (gymrs_status st = flags_for_step(e, &flags)) return st;
     StepArgs a = step_args(e, actions_dev);
-    if (gymrs_status st = log_before_step(e, &a.fold_step)) return st;
-    HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
+    if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return st;
+    HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
     e->tick += 1;
     if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
     if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick; // all lanes were re-armed
@@ -822,6 +979,7 @@ static gymrs_status rollout_impl(gymrs_engine* e, uint32_t n_steps, uint64_t act
     if (gymrs_status st = prepare_open_sums(e, vec)) return st;
     if (gymrs_status st = fold_reset_log(e)) return st; // the rollout kernel carries ep_start and the counters itself
     HIP_TRY(launch_rollout(e->kind, vec, e->flags, a, r, consts_ptr(e), e->stream));
+    if (e->flags & GYMRS_TIME_LIMIT) e->trunc_zero = false; // the kernel stored the last step's flags
     for (uint32_t k = 0; k < n_steps; ++k) { // the host copy of the uniform episode clock (Pendulum time limit)
         e->tick += 1;
         if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) {
@@ -872,7 +1030,8 @@ static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stri
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         a.tick = t;
         a.tick_base = e->tick_dev;
-        a.fold_step = (e->reset_log && t % kResetLogRows == kResetLogRows - 1) ? 1u : 0u; // a replay starts on an empty ring
+        // (a captured launch keeps the engine's own flags, time limit included: what is baked in cannot follow start_bound)
+        a.fold_step = (launch_is_logged(e, launch_flags_of(e)) && t % kResetLogRows == kResetLogRows - 1) ? 1u : 0u; // a replay starts on an empty ring
         err = launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream);
     }
     if (err == hipSuccess) err = launch_tick_advance(e->tick_dev, steps, e->stream);
@@ -911,7 +1070,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
         // a graph holds a whole number of passes over the action ring, at least 32 steps, and (reset-logged engines) a whole
         // number of ring periods, so that a replay both starts and ends on an empty ring
         uint32_t passes = (32 + n_buffers - 1) / n_buffers;
-        if (e->reset_log) {
+        if (launch_is_logged(e, launch_flags_of(e))) {
             uint32_t g = n_buffers, r = kResetLogRows; // gcd
             while (r) {
                 const uint32_t tmp = g % r;
@@ -938,12 +1097,15 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
                 done += per_graph;
                 e->tick += per_graph;
             }
+            if (e->flags & GYMRS_TIME_LIMIT) e->trunc_zero = false; // the replayed launches wrote the flags themselves
         }
     }
     for (uint32_t t = done; t < n_steps; ++t) { // eager launches (and the remainder after graph replays)
+        uint32_t flags = 0;
+        if (gymrs_status st = flags_for_step(e, &flags)) return st;
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
-        if (gymrs_status st = log_before_step(e, &a.fold_step)) return st;
-        HIP_TRY(launch_step(e->kind, e->vec, launch_flags_of(e), a, consts_ptr(e), e->stream));
+        if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return st;
+        HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
         e->tick += 1;
         if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
         if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
@@ -1155,6 +1317,8 @@ void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
     dst->nt_mode = src->nt_mode;
     dst->open_vec = src->open_vec;
     dst->trunc_held = src->trunc_held;
+    // the clone's arrays are copies of the source's: what is known about them carries over (its own refresh starts afresh)
+    limit_restart(dst, src->start_bound, src->trunc_zero);
 }
 } // namespace
 } // extern "C++"
@@ -1269,6 +1433,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     e->max_torque = h.max_torque;
     e->open_vec = (int)h.open_vec;
     e->trunc_held = -1; // whatever the arrays held before the load: rewrite the flags on the next step
+    limit_restart(e, 0, false); // nothing is known about the loaded episode clocks until a refresh has looked
     HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
     e->clean_shape = 0;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);
@@ -1426,6 +1591,10 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
     g.str("kind", e->kind == GYMRS_CARTPOLE ? "CartPole" : (e->kind == GYMRS_MOUNTAIN_CAR ? "MountainCar" : "Pendulum"));
     g.uint("n_envs", e->n).uint("global_env_id", e->gid0 + lane).uint("flags", e->flags).uint("seed", e->seed).uint("tick", e->tick);
     g.uint("max_episode_steps", max_episode_steps);
+    if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
+        g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
+        g.uint("time_limit_waits", e->age_waits).uint("time_limit_wait_us", e->age_wait_ns / 1000);
+    }
     return g;
 }
 json::Object metadata_json(std::initializer_list<const char*> modes, unsigned fps)

@@ -123,6 +123,11 @@ struct StatsArgs {
 };
 // mode 0 read, 1 clear (base = L), 2 after reset (base = 0)
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
+// The age of the oldest open episode, max over lanes of (uint32_t)(tick_ref - ep_start[lane]), from which the host derives
+// the tick before which no lane's episode started (GYMRS_TIME_LIMIT elision, gymrs_engine.hip).  partials = kStatsPartials
+// device words of scratch; the result goes to host_out2 (device-visible host memory): [0] = the age, then [1] = seq.
+hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
+                          hipStream_t stream);
 // gymrs_copy_probe: one work-item per 16 bytes; reads n_read16 and writes n_write16 16-byte items
 hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream);
 

@@ -155,6 +155,10 @@ gymrs_status gymrs_reset_pcg64(gymrs_engine* e, int has_seed, uint64_t seed, con
 /* ---- Env::step(action) (core.rs:42) --------------------------------------------------------- */
 /* actions_dev: n_envs actions on the device: uint8_t for CartPole {0,1} / MountainCar {0,1,2},
  * float for Pendulum.  Asynchronous.  Results land in the arrays below.
+ * (One exception to "asynchronous": a CartPole engine with all three flags runs the launches that cannot take any lane to
+ * the time limit without the limit check, and learns the age of the oldest open episode from the device a few launches
+ * before that knowledge runs out.  A caller that has queued steps far ahead of the GPU may wait in this call until the
+ * GPU has reached that refresh -- at most once per approach to the limit; the queue does not run dry.)
  * Alignment: a buffer aligned to lanes_per_thread * sizeof(action) bytes (4 or 8 B for u8 actions, 16 or 32 B
  * for f32; any hipMalloc / torch allocation is) is read with one vector load per work-item.  Any other address
  * is accepted too and read lane by lane (every wavefront then takes the guarded per-lane code: correct, slower).
