@@ -226,7 +226,7 @@ hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_re
 // (statistics cleared); mode 2: base = 0 (after reset(); n_partials = 0).
 __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const unsigned long long* __restrict__ partials, uint32_t n_partials,
                                                                          unsigned long long* base, int mode, int reward_sign, double n_steps,
-                                                                         double* out4)
+                                                                         double* out4, volatile double* host_out4)
 {
     unsigned long long len = 0, ep = 0;
     double ret = 0.0;
@@ -247,10 +247,13 @@ __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const u
         return;
     }
     const double flen = (double)(len - base[0]);
-    out4[0] = reward_sign != 0 ? reward_sign * flen : ret;
-    out4[1] = flen;
-    out4[2] = (double)ep;
-    out4[3] = n_steps;
+    const double r[4] = {reward_sign != 0 ? reward_sign * flen : ret, flen, (double)ep, n_steps};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        out4[j] = r[j];
+        if (host_out4) host_out4[j] = r[j]; // mapped host memory: gymrs_stats reads it after the stream sync, no copy
+    }
+    if (host_out4) __threadfence_system();
 }
 
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
@@ -264,7 +267,7 @@ hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
                            a.n_blocks, a.partials);
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(kStatsMaxBlocks), 0, stream, a.partials, grid, a.base, mode, a.reward_sign,
-                       a.n_steps, a.out4);
+                       a.n_steps, a.out4, a.host_out4);
     return hipGetLastError();
 }
 

@@ -102,6 +102,8 @@ struct gymrs_engine {
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
     double* stats_dev = nullptr;
+    volatile double* stats_host = nullptr; // mapped host memory the read-out kernel writes the same four doubles into
+    double* stats_host_dev = nullptr;      // the device's address of it
     unsigned long long* stats_acc = nullptr;  // [kStatsPartials][3] scratch of the statistics read-out
     unsigned long long* stats_base = nullptr; // [1] length sum at the last gymrs_stats_clear
     uint32_t epoch = 1;                       // ep_start value written by the last reset()
@@ -225,6 +227,7 @@ static StatsArgs stats_args(const gymrs_engine* e)
     a.reward_sign = e->kind == GYMRS_CARTPOLE ? 1 : (e->kind == GYMRS_MOUNTAIN_CAR ? -1 : 0);
     a.n_steps = e->n_steps_total;
     a.out4 = e->stats_dev;
+    a.host_out4 = e->stats_host_dev;
     return a;
 }
 
@@ -524,6 +527,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     (void)hipFree(e->tick_dev);
     (void)hipFree(e->stats_dev);
+    if (e->stats_host) (void)hipHostFree(const_cast<double*>(e->stats_host));
     (void)hipFree(e->stats_acc);
     (void)hipFree(e->stats_base);
     (void)hipFree(e->action_staging);
@@ -688,6 +692,16 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
     chk(dev_alloc(&e->stats_dev, 4));
+    {
+        void* host = nullptr;
+        if (st == GYMRS_OK && (hipHostMalloc(&host, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                               hipHostGetDevicePointer(reinterpret_cast<void**>(&e->stats_host_dev), host, 0) != hipSuccess))
+            st = fail(GYMRS_EHIP, "hipHostMalloc (statistics read-out)");
+        if (host) {
+            std::memset(host, 0, 4 * sizeof(double));
+            e->stats_host = static_cast<volatile double*>(host);
+        }
+    }
     chk(dev_alloc(&e->stats_acc, (size_t)kStatsPartials * 3));
     chk(dev_alloc(&e->stats_base, 1));
     chk(dev_alloc(&e->tick_dev, 1));
@@ -1457,8 +1471,9 @@ gymrs_status gymrs_stats(gymrs_engine* e, double out[4])
     if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_stats: NULL argument");
     double* dev = nullptr;
     if (gymrs_status st = gymrs_stats_device(e, &dev)) return st;
-    HIP_TRY(hipMemcpyAsync(out, dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream)); // the read-out kernel has written the four doubles into mapped host memory
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int j = 0; j < 4; ++j) out[j] = e->stats_host[j];
     return GYMRS_OK;
 }
 

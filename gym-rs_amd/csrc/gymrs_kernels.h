@@ -120,6 +120,7 @@ struct StatsArgs {
     int reward_sign;          // +1 CartPole, -1 MountainCar (return = +-length), 0 Pendulum (summed)
     double n_steps;
     double* out4;             // {sum_return, sum_length, n_episodes, n_steps}
+    double* host_out4;        // the same four into device-visible host memory (or NULL): a read-out without the copy engine
 };
 // mode 0 read, 1 clear (base = L), 2 after reset (base = 0)
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
