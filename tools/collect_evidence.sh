@@ -91,6 +91,14 @@ done > "$OUT/${TAG}_small_batch_graph.jsonl"
 
 # 7. A/B against the round-1 library if it was shipped (_ab/libgymrs_r01.so): same box, same call
 python tools/exp_split_streams.py > "$OUT/${TAG}_split_streams.log" 2>&1
+# 8. GYMRS_TIME_LIMIT elision (CartPole, all three flags): us per step, launches that ran without the limit, refreshes
+python tools/exp_limit_elision.py > "$OUT/${TAG}_time_limit_elision.log" 2>&1
+if [ -f _ab/libgymrs_r01.so ]; then
+    for i in 1 2; do
+        python tools/step_timer.py --lib _ab/libgymrs_r01.so --flags 7 --reps 5
+        python tools/step_timer.py --flags 7 --reps 5
+    done >> "$OUT/${TAG}_time_limit_elision.log" 2>&1
+fi
 if [ -f _ab/libgymrs_r01.so ]; then
     for i in 1 2 3; do
         python tools/step_timer.py --lib _ab/libgymrs_r01.so --reps 5
