@@ -97,10 +97,18 @@ struct gymrs_engine {
     int log_vec = 4; // lanes per work-item of the launches that wrote the pending rows
     void* pool = nullptr; // one allocation holding every per-lane array (see engine_create)
     size_t pool_bytes = 0;
+    // Engines of up to kHostPoolMaxLanes lanes (the single-env mirrors: one lane) keep that allocation in mapped host
+    // memory: the kernels reach it over the bus, and the host reads a step's results (state, reward, flags) and writes
+    // actions and states with plain loads and stores after a stream synchronisation instead of three to five copy
+    // commands (single-env step through the Python mirror: 156 -> ~40 us).
+    char* pool_host = nullptr;       // host address of the pool (NULL = the pool is device memory)
+    char* staging_host = nullptr;    // host address of action_staging when that is mapped host memory too
     int vec = 4; // lanes per work-item
     int nt_mode = 0; // 0 = automatic, 1 = always non-temporal, 2 = never
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
+    volatile uint32_t* err_seen = nullptr; // mapped host word: a kernel that saw an invalid action sets it (StepArgs::err_seen)
+    uint32_t* err_seen_dev = nullptr;
     double* stats_dev = nullptr;
     volatile double* stats_host = nullptr; // mapped host memory the read-out kernel writes the same four doubles into
     double* stats_host_dev = nullptr;      // the device's address of it
@@ -155,6 +163,15 @@ static const void* consts_ptr(const gymrs_engine* e)
 
 static size_t action_size(gymrs_env_kind kind) { return kind == GYMRS_PENDULUM ? sizeof(float) : sizeof(uint8_t); }
 
+constexpr uint64_t kHostPoolMaxLanes = 64;
+
+// Host address of one of the pool's arrays (engines whose pool is mapped host memory).
+template <class T>
+static T* host_of(const gymrs_engine* e, T* dev)
+{
+    return reinterpret_cast<T*>(e->pool_host + (reinterpret_cast<char*>(dev) - static_cast<char*>(e->pool)));
+}
+
 static uint64_t os_entropy()
 {
     // seeding.rs:22 `thread_rng().gen()`: a fresh seed from the OS
@@ -199,6 +216,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.reset_log_row_words = e->log_row_words;
     a.fold_step = 0;
     a.err = e->err;
+    a.err_seen = e->err_seen_dev;
     a.n = e->n;
     // the vector load of a work-item's actions needs vec * sizeof(action) alignment; any other address is read lane by
     // lane (n_fast = 0 sends every wavefront through the guarded code)
@@ -516,7 +534,10 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
-    (void)hipFree(e->pool); // all per-lane arrays
+    if (e->pool_host)
+        (void)hipHostFree(e->pool_host);
+    else
+        (void)hipFree(e->pool); // all per-lane arrays
     (void)hipFree(e->block_stats);
     (void)hipFree(e->reset_log);
     (void)hipFree(e->age_dev);
@@ -524,13 +545,17 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipFree(e->wave_open);
     (void)hipFree(e->wave_clean);
     (void)hipFree(e->err);
+    if (e->err_seen) (void)hipHostFree(const_cast<uint32_t*>(e->err_seen));
     if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
     (void)hipFree(e->tick_dev);
     (void)hipFree(e->stats_dev);
     if (e->stats_host) (void)hipHostFree(const_cast<double*>(e->stats_host));
     (void)hipFree(e->stats_acc);
     (void)hipFree(e->stats_base);
-    (void)hipFree(e->action_staging);
+    if (e->staging_host)
+        (void)hipHostFree(e->staging_host);
+    else
+        (void)hipFree(e->action_staging);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return GYMRS_OK;
@@ -642,7 +667,20 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
         const size_t at_reward = place(npad * 4), at_done = place(npad), at_trunc = place(npad), at_beyond = place(npad),
                      at_start = place(npad * 4);
         void* pool = nullptr;
-        hipError_t perr = hipMalloc(&pool, off + 256);
+        hipError_t perr;
+        if (n_envs <= kHostPoolMaxLanes) {
+            void* host = nullptr;
+            perr = hipHostMalloc(&host, off + 256, hipHostMallocMapped | hipHostMallocCoherent);
+            if (perr == hipSuccess) perr = hipHostGetDevicePointer(&pool, host, 0);
+            if (perr == hipSuccess) {
+                std::memset(host, 0, off + 256);
+                e->pool_host = static_cast<char*>(host);
+            } else if (host) {
+                (void)hipHostFree(host);
+            }
+        } else {
+            perr = hipMalloc(&pool, off + 256);
+        }
         if (perr != hipSuccess) {
             delete e;
             return fail(perr == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("hipMalloc: ") + hipGetErrorString(perr));
@@ -691,6 +729,16 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->wave_open, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->wave_clean, (size_t)e->n_stat_blocks));
     chk(dev_alloc(&e->err, 2));
+    {
+        void* host = nullptr;
+        if (st == GYMRS_OK && (hipHostMalloc(&host, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+                               hipHostGetDevicePointer(reinterpret_cast<void**>(&e->err_seen_dev), host, 0) != hipSuccess))
+            st = fail(GYMRS_EHIP, "hipHostMalloc (error flag)");
+        if (host) {
+            *static_cast<uint32_t*>(host) = 0;
+            e->err_seen = static_cast<volatile uint32_t*>(host);
+        }
+    }
     chk(dev_alloc(&e->stats_dev, 4));
     {
         void* host = nullptr;
@@ -1023,6 +1071,17 @@ gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host)
     if (!e || !actions_host) return fail(GYMRS_EINVAL, "gymrs_step_host: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
     const size_t bytes = (size_t)e->n * action_size(e->kind);
+    if (e->pool_host) { // small engine: the staging buffer is mapped host memory, the "copy" a memcpy
+        if (!e->action_staging) {
+            void* host = nullptr;
+            HIP_TRY(hipHostMalloc(&host, ((bytes + 63) & ~(size_t)63), hipHostMallocMapped | hipHostMallocCoherent));
+            e->staging_host = static_cast<char*>(host);
+            HIP_TRY(hipHostGetDevicePointer(&e->action_staging, host, 0));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream)); // a step still in flight may be reading the buffer
+        std::memcpy(e->staging_host, actions_host, bytes);
+        return gymrs_step(e, e->action_staging);
+    }
     if (!e->action_staging) HIP_TRY(hipMalloc(&e->action_staging, ((bytes + 63) & ~(size_t)63)));
     HIP_TRY(hipMemcpyAsync(e->action_staging, actions_host, bytes, hipMemcpyHostToDevice, e->stream));
     return gymrs_step(e, e->action_staging);
@@ -1132,9 +1191,13 @@ gymrs_status gymrs_sync(gymrs_engine* e)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*e->err_seen == 0) return GYMRS_OK; // no kernel saw an invalid action: nothing to fetch
     uint32_t err[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(err, e->err, sizeof(err), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    *e->err_seen = 0;
     if (err[0] != 0) {
         static const uint32_t err_init[2] = {0u, 0xffffffffu};
         HIP_TRY(hipMemcpyAsync(e->err, err_init, sizeof(err_init), hipMemcpyHostToDevice, e->stream));
@@ -1215,6 +1278,11 @@ gymrs_status gymrs_get_state(gymrs_engine* e, uint64_t first, uint64_t count, fl
     if (!e || !host_out) return fail(GYMRS_EINVAL, "gymrs_get_state: NULL argument");
     if (gymrs_status st = range_check(e, first, count, "gymrs_get_state")) return st;
     HIP_TRY(hipSetDevice(e->device));
+    if (e->pool_host) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int j = 0; j < e->state_dim; ++j) std::memcpy(host_out + (size_t)j * count, host_of(e, e->s[j]) + first, count * sizeof(float));
+        return GYMRS_OK;
+    }
     for (int j = 0; j < e->state_dim; ++j)
         HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, e->s[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1226,6 +1294,13 @@ gymrs_status gymrs_set_state(gymrs_engine* e, uint64_t first, uint64_t count, co
     if (!e || !host_in) return fail(GYMRS_EINVAL, "gymrs_set_state: NULL argument");
     if (gymrs_status st = range_check(e, first, count, "gymrs_set_state")) return st;
     HIP_TRY(hipSetDevice(e->device));
+    if (e->pool_host) { // (like the assignment below, this touches nothing but the state)
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int j = 0; j < e->state_dim; ++j) std::memcpy(host_of(e, e->s[j]) + first, host_in + (size_t)j * count, count * sizeof(float));
+        if (e->kind == GYMRS_PENDULUM)
+            for (uint64_t i = 0; i < count; ++i) sincosf_(host_in[i], host_of(e, e->obs_sin) + first + i, host_of(e, e->obs_cos) + first + i);
+        return GYMRS_OK;
+    }
     for (int j = 0; j < e->state_dim; ++j)
         HIP_TRY(hipMemcpyAsync(e->s[j] + first, host_in + (size_t)j * count, count * sizeof(float), hipMemcpyHostToDevice, e->stream));
     // like assigning the pub `state` field in the reference, this touches nothing else: the episode
@@ -1248,6 +1323,13 @@ gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t cou
     if (!e) return fail(GYMRS_EINVAL, "gymrs_get_step_result: engine is NULL");
     if (gymrs_status st = range_check(e, first, count, "gymrs_get_step_result")) return st;
     HIP_TRY(hipSetDevice(e->device));
+    if (e->pool_host) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (reward) std::memcpy(reward, host_of(e, e->reward) + first, count * sizeof(float));
+        if (done) std::memcpy(done, host_of(e, e->done) + first, count);
+        if (truncated) std::memcpy(truncated, host_of(e, e->truncated) + first, count);
+        return GYMRS_OK;
+    }
     if (reward) HIP_TRY(hipMemcpyAsync(reward, e->reward + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (done) HIP_TRY(hipMemcpyAsync(done, e->done + first, count, hipMemcpyDeviceToHost, e->stream));
     if (truncated) HIP_TRY(hipMemcpyAsync(truncated, e->truncated + first, count, hipMemcpyDeviceToHost, e->stream));
@@ -1333,6 +1415,7 @@ void copy_scalars(gymrs_engine* dst, const gymrs_engine* src)
     dst->trunc_held = src->trunc_held;
     // the clone's arrays are copies of the source's: what is known about them carries over (its own refresh starts afresh)
     limit_restart(dst, src->start_bound, src->trunc_zero);
+    *dst->err_seen = 1u; // the error words are copied with the arrays: have the next gymrs_sync look at them
 }
 } // namespace
 } // extern "C++"
@@ -1351,7 +1434,7 @@ gymrs_status gymrs_engine_clone(gymrs_engine* src, gymrs_engine** out)
     hipError_t err = hipStreamSynchronize(src->stream); // everything queued on the source has happened
     const std::vector<Segment> from = snapshot_segments(src), to = snapshot_segments(dst);
     for (size_t i = 0; i < from.size() && err == hipSuccess; ++i)
-        err = hipMemcpyAsync(to[i].dev, from[i].dev, from[i].bytes, hipMemcpyDeviceToDevice, dst->stream);
+        err = hipMemcpyAsync(to[i].dev, from[i].dev, from[i].bytes, hipMemcpyDefault, dst->stream); // (a small engine's pool is mapped host memory)
     if (err == hipSuccess) err = hipStreamSynchronize(dst->stream);
     if (err != hipSuccess) {
         gymrs_engine_destroy(dst);
@@ -1405,7 +1488,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
     std::memcpy(p, &h, sizeof(h));
     p += sizeof(h);
     for (const Segment& sg : snapshot_segments(e)) {
-        HIP_TRY(hipMemcpyAsync(p, sg.dev, sg.bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(p, sg.dev, sg.bytes, hipMemcpyDefault, e->stream));
         p += sg.bytes;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1431,7 +1514,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     if (gymrs_status st = fold_reset_log(e)) return st; // empties the ring; what it folded into is overwritten below
     const char* p = static_cast<const char*>(host_buf) + sizeof(h);
     for (const Segment& sg : snapshot_segments(e)) {
-        HIP_TRY(hipMemcpyAsync(sg.dev, p, sg.bytes, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(sg.dev, p, sg.bytes, hipMemcpyDefault, e->stream));
         p += sg.bytes;
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1448,6 +1531,7 @@ gymrs_status gymrs_snapshot_load(gymrs_engine* e, const void* host_buf, uint64_t
     e->open_vec = (int)h.open_vec;
     e->trunc_held = -1; // whatever the arrays held before the load: rewrite the flags on the next step
     limit_restart(e, 0, false); // nothing is known about the loaded episode clocks until a refresh has looked
+    *e->err_seen = 1u;          // the error words came with the blob: have the next gymrs_sync look at them
     HIP_TRY(hipMemsetAsync(e->wave_clean, 0, (size_t)e->n_stat_blocks * sizeof(uint32_t), e->stream)); // and the rewards
     e->clean_shape = 0;
     std::memcpy(&e->consts, h.consts, h.consts_bytes);

@@ -38,6 +38,8 @@ struct StepArgs {
     uint32_t reset_log_row_words;
     uint32_t fold_step;            // this launch folds the ring (wave-uniform branch in step_block)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
+    uint32_t* err_seen; // mapped host word a wave that saw an invalid action sets to 1: gymrs_sync looks there first and
+                        // fetches err[] only then (no device-to-host copy per synchronisation)
     uint64_t n;         // lanes in this engine
     uint64_t n_fast;    // n, or 0 when the action buffer is not aligned for the vector load (step_kernel)
     uint64_t gid0;      // global id of lane 0

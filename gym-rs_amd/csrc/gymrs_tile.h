@@ -388,6 +388,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
         if (n_bad) {
             atomicAdd(&a.err[0], n_bad);
             atomicMin(&a.err[1], first_bad);
+            *a.err_seen = 1u;
         }
         out.reward_is_const = __all(n_bad == 0); // an invalid action leaves the lane untouched and pays 0
     }

@@ -211,3 +211,58 @@ def test_philox_known_answer_on_the_gpu(gymrs, twin, golden):
             gid = gid0 + lane
             want = twin.philox([gid & 0xFFFFFFFF, gid >> 32, 0, 0], [seed & 0xFFFFFFFF, seed >> 32])
             assert [int(v) for v in got[:, lane]] == [int(w) >> 8 for w in want], (gid0, seed, lane)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_small_engines_in_mapped_host_memory_match_large_ones(gymrs, kind):
+    """Engines of up to 64 lanes keep their arrays in mapped host memory (results are read with plain loads after a stream
+    synchronisation: the single-env mirrors step 3.5x faster); lane i of a 64-lane engine must do exactly what lane i of a
+    65-lane engine (device memory) does -- through steps, set_state, clone, snapshot, the fused rollout and an invalid action."""
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | gymrs.TIME_LIMIT
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 17
+    small = gymrs.BatchedEngine(kind, 64, flags=flags, params=p, global_env_offset=5)
+    large = gymrs.BatchedEngine(kind, 65, flags=flags, params=p, global_env_offset=5)
+    dtype = np.float32 if kind == 2 else np.uint8
+    rs = np.random.default_rng(kind)
+
+    def acts():
+        return rs.uniform(-2, 2, 65).astype(np.float32) if kind == 2 else rs.integers(0, 2, 65).astype(np.uint8)
+
+    def same(a, b):
+        assert np.array_equal(a.get_state().view(np.uint32), b.get_state()[:, :64].view(np.uint32))
+        ra, rb = a.get_step_result(), b.get_step_result()
+        for x, y in zip(ra, rb):
+            assert np.array_equal(x, y[:64])
+
+    for e in (small, large):
+        e.reset(seed=9)
+    same(small, large)
+    for t in range(40):
+        a = acts()
+        small.step_host(a[:64])
+        large.step_host(a)
+        same(small, large)
+    st = large.get_state().copy()
+    st[0, :] += 0.01
+    small.set_state(st[:, :64])
+    large.set_state(st)
+    c_small, c_large = small.clone(), large.clone()
+    blob = small.snapshot()
+    for e in (small, large, c_small, c_large):
+        e.rollout(23, action_seed=4, action_t0=7)
+    same(small, large)
+    same(c_small, c_large)
+    r = gymrs.BatchedEngine(kind, 64, flags=flags, params=p)
+    r.restore(blob)
+    r.rollout(23, action_seed=4, action_t0=7)
+    same(r, large)
+    assert np.array_equal(small.stats()[1:], c_small.stats()[1:])
+    if kind != 2:  # an invalid action is still reported (through the mapped error flag)
+        bad = np.zeros(64, dtype)
+        bad[3] = 7
+        with pytest.raises(gymrs.InvalidActionError):
+            small.step_host(bad)
+        small.step_host(np.zeros(64, dtype))  # and the engine goes on
+    for e in (small, large, c_small, c_large, r):
+        e.close()
