@@ -420,6 +420,8 @@ def run_rank(args, info, backend, make_collective=None):
                 "event_ms_per_repetition": kernels,
                 "statistic": "median over repetitions of the max over ranks",
                 "stats_readout_us": stats_readout_us,
+                # CPUs this rank's launching thread and the HIP runtime's helpers were confined to (None = not pinned)
+                "cpu_affinity": getattr(args, "cpu_affinity", None),
             },
             "ranks": per_rank,
             "roofline": {
@@ -506,6 +508,7 @@ def run_rank(args, info, backend, make_collective=None):
             elif note:
                 roof["note"] = note
             out["roofline"] = roof
+        gymrs.sharded.restore_cpus(getattr(args, "cpu_affinity_before", None))  # the CPU baseline may use every core
         if info.world == 1 and args.cpu_seconds > 0 and hasattr(backend, "cpu_baseline"):
             out["cpu_baseline"] = backend.cpu_baseline(kind, args.cpu_seconds)
         elif info.world == 1 and args.cpu_seconds > 0:
@@ -528,6 +531,9 @@ def main(argv=None) -> int:
         if info.is_root:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={info.world} ranks", file=sys.stderr)
         return 2
+    # a few CPUs per rank for the launching thread and the HIP runtime's helpers (sharded.pin_rank_to_cpus says why);
+    # the CPU baseline leg gets the full mask back
+    args.cpu_affinity, args.cpu_affinity_before = sharded.pin_rank_to_cpus(info.local_rank)
     backend = HipBackend(args, info)
     out = run_rank(args, info, backend)
     if out is not None:
