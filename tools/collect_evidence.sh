@@ -9,6 +9,8 @@ OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 REPO=$PWD
+# bench.py confines itself to 4 CPUs (sharded.pin_rank_to_cpus); the developer tools get the same treatment from outside
+PIN="taskset -c 4-7"
 SHA=$(python -c "import bench; print(bench.kernel_source_sha16())")
 echo "kernel_source_sha16 $SHA" > "$OUT/${TAG}_sha.txt"
 
@@ -80,9 +82,9 @@ for env in cartpole mountain_car pendulum; do
 done
 
 # 6. batch-size sweep against the in-library copy probe (DRAM-resident regime), small batches with graph replay
-python tools/size_sweep.py --sizes 14,16,18,20,21,22,23,24,25 > "$OUT/${TAG}_size_sweep.log" 2>&1
-python tools/size_sweep.py --sizes 20,22,23,24 --nt 1 >> "$OUT/${TAG}_size_sweep.log" 2>&1
-python tools/size_sweep.py --sizes 20,22,23,24 --nt 2 >> "$OUT/${TAG}_size_sweep.log" 2>&1
+$PIN python tools/size_sweep.py --sizes 14,16,18,20,21,22,23,24,25 > "$OUT/${TAG}_size_sweep.log" 2>&1
+$PIN python tools/size_sweep.py --sizes 20,22,23,24 --nt 1 >> "$OUT/${TAG}_size_sweep.log" 2>&1
+$PIN python tools/size_sweep.py --sizes 20,22,23,24 --nt 2 >> "$OUT/${TAG}_size_sweep.log" 2>&1
 for n in 1024 16384 131072; do
     for g in "" "--graph"; do
         python bench.py --n-envs $n --steps 2000 --warmup 400 --cpu-seconds 0 --no-probe $g 2>/dev/null
@@ -90,20 +92,22 @@ for n in 1024 16384 131072; do
 done > "$OUT/${TAG}_small_batch_graph.jsonl"
 
 # 7. A/B against the round-1 library if it was shipped (_ab/libgymrs_r01.so): same box, same call
-python tools/exp_split_streams.py > "$OUT/${TAG}_split_streams.log" 2>&1
+$PIN python tools/exp_split_streams.py > "$OUT/${TAG}_split_streams.log" 2>&1
 # 8. GYMRS_TIME_LIMIT elision (CartPole, all three flags): us per step, launches that ran without the limit, refreshes
-python tools/exp_limit_elision.py > "$OUT/${TAG}_time_limit_elision.log" 2>&1
+$PIN python tools/exp_limit_elision.py > "$OUT/${TAG}_time_limit_elision.log" 2>&1
 if [ -f _ab/libgymrs_r01.so ]; then
     for i in 1 2; do
-        python tools/step_timer.py --lib _ab/libgymrs_r01.so --flags 7 --reps 5
-        python tools/step_timer.py --flags 7 --reps 5
+        $PIN python tools/step_timer.py --lib _ab/libgymrs_r01.so --flags 7 --reps 5
+        $PIN python tools/step_timer.py --flags 7 --reps 5
     done >> "$OUT/${TAG}_time_limit_elision.log" 2>&1
 fi
 if [ -f _ab/libgymrs_r01.so ]; then
     for i in 1 2 3; do
-        python tools/step_timer.py --lib _ab/libgymrs_r01.so --reps 5
-        python tools/step_timer.py --reps 5
+        $PIN python tools/step_timer.py --lib _ab/libgymrs_r01.so --reps 5
+        $PIN python tools/step_timer.py --reps 5
     done > "$OUT/${TAG}_ab_vs_round1.log" 2>&1
 fi
+# 9. what the pinning is worth: the driver's command alternately pinned and not
+bash tools/exp_cpu_pinning.sh > "$OUT/${TAG}_cpu_pinning.log" 2>&1
 du -sh "$OUT" | tail -1
 echo evidence-done
