@@ -531,13 +531,19 @@ def main(argv=None) -> int:
         if info.is_root:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={info.world} ranks", file=sys.stderr)
         return 2
+    # stdout carries ONE line, rank 0's JSON: whatever else writes to file descriptor 1 in a rank process (RCCL's version
+    # banner -- flushed at exit, i.e. AFTER the JSON line --, gloo's connection chatter) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     # a few CPUs per rank for the launching thread and the HIP runtime's helpers (sharded.pin_rank_to_cpus says why);
     # the CPU baseline leg gets the full mask back
     args.cpu_affinity, args.cpu_affinity_before = sharded.pin_rank_to_cpus(info.local_rank)
     backend = HipBackend(args, info)
     out = run_rank(args, info, backend)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
     return 0
 
 

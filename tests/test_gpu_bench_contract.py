@@ -19,6 +19,8 @@ def run(cmd, env=None):
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    # stdout carries that ONE line and nothing else (RCCL's banner and gloo's chatter are sent to stderr)
+    assert out.stdout.strip().splitlines() == lines, out.stdout[-2000:]
     return json.loads(lines[0])
 
 
