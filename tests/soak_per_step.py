@@ -29,3 +29,26 @@ for chunk, graph in ((10001, False), (20000, True), (9999, False)):
     assert np.array_equal(eng.stats(), tw.stats()), (done, eng.stats(), tw.stats())
     assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32)), done
 print("per-step soak ok:", done, "steps", eng.stats(), f"{time.time()-t0:.1f}s")
+
+# The same with all three flags and a 45-step time limit that random-policy episodes reach now and then: launches with and
+# without the limit alternate (GYMRS_TIME_LIMIT elision), refreshes of the bound with back-off,
+# graph replays (which keep the limit) in the middle.
+import json
+p = gymrs.engine.default_params(0)
+p.max_episode_steps = 45
+flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | gymrs.TIME_LIMIT
+eng = gymrs.BatchedEngine(0, n, flags=flags, params=p, global_env_offset=77)
+tw = TwinEngine(tw_lib, 0, n, p, flags=flags, gid0=77)
+eng.reset(seed=3); tw.reset(3)
+t0 = time.time()
+done = 0
+for chunk, graph in ((9001, False), (6000, True), (9999, False)):
+    eng.step_many(bufs.data_ptr(), n, nbuf, chunk, use_graph=graph)
+    for t in range(chunk): tw.step(acts[t % nbuf])
+    done += chunk
+    assert np.array_equal(eng.stats(), tw.stats()), (done, eng.stats(), tw.stats())
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32)), done
+    assert np.array_equal(eng.get_step_result()[2], tw.get_result()[2]), done
+extra = json.loads(eng.env_json(0))["gymrs"]
+assert 0 < extra["time_limit_elided_launches"] < done
+print("time-limit soak ok:", done, "steps", eng.stats(), {k: v for k, v in extra.items() if k.startswith("time_limit")}, f"{time.time()-t0:.1f}s")
