@@ -200,3 +200,37 @@ def test_plain_multi_gpu_form_spawns_ranks_and_fails_loudly_without_gpus():
     assert res.returncode != 0
     assert "no GPU visible; the stepper has no CPU fallback" in text
     assert "torch.distributed" in text or "ChildFailedError" in text or "elastic" in text  # it went through the launcher
+
+
+def test_rank_cpu_pinning_blocks():
+    """sharded.pin_rank_to_cpus: a different block of 4 of the allowed CPUs per local rank, the previous mask handed back for
+    restore_cpus; switched off by GYMRS_NO_CPU_PIN=1.  Run in a child process: the affinity of the test runner stays."""
+    code = r'''
+import importlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+sh = importlib.import_module("gym-rs_amd").sharded
+allowed = sorted(os.sched_getaffinity(0))
+out = {"allowed": allowed, "ranks": []}
+for rank in (0, 1, 5):
+    mine, before = sh.pin_rank_to_cpus(rank)
+    out["ranks"].append({"mine": mine, "before": before, "now": sorted(os.sched_getaffinity(0))})
+    sh.restore_cpus(before)
+    assert sorted(os.sched_getaffinity(0)) == allowed
+mine, before = sh.pin_rank_to_cpus(0, env={"GYMRS_NO_CPU_PIN": "1"})
+out["off"] = [mine, sorted(os.sched_getaffinity(0)) == allowed]
+print(json.dumps(out))
+'''
+    res = subprocess.run([sys.executable, "-c", code, str(ROOT)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    allowed = out["allowed"]
+    if len(allowed) <= 4:
+        assert all(r["mine"] is None for r in out["ranks"])  # nothing to choose from: left alone
+        return
+    blocks = len(allowed) // 4
+    for rank, r in zip((0, 1, 5), out["ranks"]):
+        start = (rank % blocks) * 4
+        assert r["mine"] == allowed[start:start + 4] == r["now"] and r["before"] == allowed
+    if blocks >= 2:
+        assert out["ranks"][0]["mine"] != out["ranks"][1]["mine"]
+    assert out["off"] == [None, True]
