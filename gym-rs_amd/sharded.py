@@ -84,7 +84,8 @@ def pin_rank_to_cpus(local_rank: int, width: int = 4, env=None):
     return (the new CPU list, the previous one) -- or (None, previous) when pinning is switched off
     (``GYMRS_NO_CPU_PIN=1``) or not possible.  Call it BEFORE the HIP runtime starts: its helper threads inherit the mask.
 
-    Why: a per-step launch costs the host 4-5 us and a 2^20-lane step lasts 6.4, so the launching thread has little slack.
+    Why: a per-step launch costs the launching thread 2.8 us when it stays on its core and 3.1-5.4 us when the scheduler
+    moves it around (tools/exp_host_cost.py); a 2^20-lane step lasts 4 (MountainCar) to 6.4 us (CartPole): little slack.
     Left to the scheduler on a 256-CPU host, one process in two ran 2-6 % slower (6.5-6.9 instead of 6.4 us per step;
     MountainCar's 4 us launches 4.2-5.2 instead of 3.95), whatever the socket; confined to a few cores every process
     measured the fast figure (profiles/r02_cpu_pinning.log).  Which NUMA node the block lies on made no difference."""
