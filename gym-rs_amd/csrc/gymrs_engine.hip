@@ -152,6 +152,13 @@ struct gymrs_engine {
 
 static RcclApi g_rccl;
 
+// The engine that launched the last per-step kernel on each device.  An engine that takes over from ANOTHER one finds its
+// arrays pushed out of the Infinity Cache, and launches with the non-temporal hint bring them back only slowly (6.9 instead
+// of 6.45 us per 2^20-lane CartPole step for ~4000 steps, profiles/r02_mall_residency.log): its first launch after the
+// take-over uses plain, allocating accesses once.  (Periodically doing so for one engine costs more than it brings.)
+constexpr int kMaxDevices = 64;
+static std::atomic<const gymrs_engine*> g_last_stepper[kMaxDevices];
+
 static const void* consts_ptr(const gymrs_engine* e)
 {
     switch (e->kind) {
@@ -338,6 +345,8 @@ static gymrs_status wait_for_age(gymrs_engine* e)
 static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
 {
     uint32_t flags = launch_flags_of(e);
+    if (e->device >= 0 && e->device < kMaxDevices && g_last_stepper[e->device].exchange(e, std::memory_order_relaxed) != e && e->nt_mode == 0)
+        flags &= ~kFlagNonTemporal; // taking over the device from another engine (or first launch): install the lines, see above
     *out = flags;
     if (!e->limit_elidable) return GYMRS_OK;
     const uint64_t limit = limit_of(e);
@@ -534,6 +543,10 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    if (e->device >= 0 && e->device < kMaxDevices) { // a later engine at the same address must not pass for this one
+        const gymrs_engine* self = e;
+        g_last_stepper[e->device].compare_exchange_strong(self, nullptr, std::memory_order_relaxed);
+    }
     if (e->pool_host)
         (void)hipHostFree(e->pool_host);
     else
@@ -1165,6 +1178,7 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
             HIP_TRY(hipMemcpyAsync(e->tick_dev, &tick_now, sizeof(tick_now), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream)); // tick_now is a stack variable; the copy must finish before return
             if (gymrs_status st = fold_reset_log(e)) return st; // the captured fold steps assume an empty ring at the start
+            if (e->device >= 0 && e->device < kMaxDevices) g_last_stepper[e->device].store(e, std::memory_order_relaxed);
             while (n_steps - done >= per_graph) {
                 HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
                 done += per_graph;

@@ -27,6 +27,9 @@ def series(e, label, reps=10):
 
 
 series(a, "A warm-up", 16)
+series(b, "B after A (library's own take-over step)")
+series(a, "A after B (library's own take-over step)")
+series(b, "B after A (library's own take-over step)")
 series(b, "B after A (nothing done)")
 series(a, "A after B (nothing done)")
 for k in (1, 8, 64):
