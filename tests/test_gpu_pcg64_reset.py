@@ -127,3 +127,21 @@ def test_c_abi_argument_checks(gymrs):
         a = eng.get_state().copy()
         assert lib.gymrs_reset_pcg64(eng._h, 1, used.value, None, None, None) == 0
         assert np.array_equal(eng.get_state(), a)  # the echoed seed reproduces the draw
+
+
+def test_full_size_pcg64_reset(gymrs, oracle):
+    """2^20 lanes (BASELINE configs[1]): the shift property lane i of seed s + 1 = lane i + 1 of seed s over the whole batch,
+    2000 sampled lanes against the oracle, range and moments of the draw."""
+    n, seed, gid0 = 1 << 20, 123456789, 1 << 35
+    with gymrs.BatchedEngine(0, n, flags=0, global_env_offset=gid0) as eng:
+        eng.reset_pcg64(seed)
+        a = eng.get_state().copy()
+        eng.reset_pcg64(seed + 1)
+        b = eng.get_state()
+        assert np.array_equal(a[:, 1:].view(np.uint32), b[:, :-1].view(np.uint32))
+        idx = np.random.default_rng(0).integers(0, n, 2000)
+        want = want_states(oracle, 0, [(seed + gid0 + int(i)) & M64 for i in idx])
+        assert np.array_equal(a[:, idx].view(np.uint32), want.view(np.uint32))
+        assert a.min() >= np.float32(-0.05) and a.max() <= np.float32(0.05)
+        assert abs(float(a.mean())) < 2e-4 and abs(float(a.std()) - 0.1 / np.sqrt(12)) < 2e-4
+        assert abs(np.corrcoef(a)[0, 1]) < 5e-3  # x and x_dot of one lane come from consecutive outputs of one generator
