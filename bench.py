@@ -538,7 +538,7 @@ def main(argv=None) -> int:
     os.dup2(2, 1)
     # a few CPUs per rank for the launching thread and the HIP runtime's helpers (sharded.pin_rank_to_cpus says why);
     # the CPU baseline leg gets the full mask back
-    args.cpu_affinity, args.cpu_affinity_before = sharded.pin_rank_to_cpus(info.local_rank)
+    args.cpu_affinity, args.cpu_affinity_before = sharded.pin_rank_to_cpus(info.local_rank, n_local_ranks=info.world)
     backend = HipBackend(args, info)
     out = run_rank(args, info, backend)
     if out is not None:

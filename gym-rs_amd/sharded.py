@@ -79,7 +79,7 @@ def spawn_ranks(script: str, argv: Sequence[str], n_gpus: int, port: Optional[in
     return subprocess.call(spawn_command(script, argv, n_gpus, port), env=env)
 
 
-def pin_rank_to_cpus(local_rank: int, width: int = 4, env=None):
+def pin_rank_to_cpus(local_rank: int, width: int = 4, env=None, n_local_ranks: int = 1):
     """Pin the calling process to ``width`` consecutive CPUs of those it may use, a different block per local rank, and
     return (the new CPU list, the previous one) -- or (None, previous) when pinning is switched off
     (``GYMRS_NO_CPU_PIN=1``) or not possible.  Call it BEFORE the HIP runtime starts: its helper threads inherit the mask.
@@ -94,6 +94,8 @@ def pin_rank_to_cpus(local_rank: int, width: int = 4, env=None):
         previous = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         return None, None
+    if n_local_ranks > 1:  # few CPUs for many ranks: narrower blocks rather than shared ones
+        width = max(1, min(width, len(previous) // int(n_local_ranks)))
     if env.get("GYMRS_NO_CPU_PIN") == "1" or len(previous) <= width:
         return None, previous
     blocks = len(previous) // width
