@@ -95,6 +95,7 @@ done > "$OUT/${TAG}_small_batch_graph.jsonl"
 $PIN python tools/exp_split_streams.py > "$OUT/${TAG}_split_streams.log" 2>&1
 # 8. GYMRS_TIME_LIMIT elision (CartPole, all three flags): us per step, launches that ran without the limit, refreshes
 $PIN python tools/exp_limit_elision.py > "$OUT/${TAG}_time_limit_elision.log" 2>&1
+$PIN python tools/exp_exact_limit.py >> "$OUT/${TAG}_time_limit_elision.log" 2>&1
 if [ -f _ab/libgymrs_r01.so ]; then
     for i in 1 2; do
         $PIN python tools/step_timer.py --lib _ab/libgymrs_r01.so --flags 7 --reps 5
