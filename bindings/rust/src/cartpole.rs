@@ -58,6 +58,9 @@ pub struct CartPoleEnv {
     rand_random: Pcg64,
 }
 
+/// What the reference's metadata lists (cartpole.rs:265); only `RenderMode::None` is honoured here.
+const RENDER_MODES: &[RenderMode] = &[RenderMode::Human, RenderMode::RgbArray];
+
 fn observation(st: &[f32]) -> CartPoleObservation {
     CartPoleObservation::new(
         OrderedFloat(st[0] as f64),
@@ -91,7 +94,7 @@ impl CartPoleEnv {
             observation_space: BoxR::new(-high, high),
             render_mode,
             state,
-            metadata: Metadata::default(),
+            metadata: Metadata::new(RENDER_MODES, 50), // cartpole.rs:265-269 (its Default impl is for the reference's own type)
             gravity: OrderedFloat(p.gravity),
             masscart: OrderedFloat(p.masscart),
             masspole: OrderedFloat(p.masspole),

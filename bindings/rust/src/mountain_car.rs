@@ -47,6 +47,9 @@ pub struct MountainCarEnv {
     rand_random: Pcg64,
 }
 
+/// What the reference's metadata lists (mountain_car.rs:108-113); only `RenderMode::None` is honoured here.
+const RENDER_MODES: &[RenderMode] = &[RenderMode::Human, RenderMode::RgbArray, RenderMode::SingleRgbArray, RenderMode::None];
+
 fn observation(st: &[f32]) -> MountainCarObservation {
     MountainCarObservation::new(OrderedFloat(st[0] as f64), OrderedFloat(st[1] as f64))
 }
@@ -78,7 +81,7 @@ impl MountainCarEnv {
                 MountainCarObservation::new(OrderedFloat(p.max_position), OrderedFloat(p.max_speed)),
             ),
             state,
-            metadata: Metadata::default(),
+            metadata: Metadata::new(RENDER_MODES, 30), // mountain_car.rs:108-118 (its Default impl is for the reference's own type)
             pushed: p,
             engine,
             rand_random: rng,
@@ -124,7 +127,7 @@ impl Env for MountainCarEnv {
         self.engine.step_host(&[action as u8]);
         self.state = observation(&self.engine.state(0, 1));
         let r = self.engine.lane_result(0);
-        ActionReward { observation: self.state, reward: OrderedFloat(r.reward as f64), done: r.done, truncated: false, info: Some(()) }
+        ActionReward { observation: self.state, reward: OrderedFloat(r.reward as f64), done: r.done, truncated: false, info: None } // mountain_car.rs:433
     }
 
     fn reset(
