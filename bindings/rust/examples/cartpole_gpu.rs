@@ -4,7 +4,7 @@ use gym_rs::core::Env;
 use gym_rs::utils::renderer::RenderMode;
 use gym_rs_amd::cartpole::CartPoleEnv;
 use gym_rs_amd::engine::{Engine, Kind};
-use gym_rs_amd::ffi::{CartPoleParams, GYMRS_AUTO_RESET, GYMRS_TRACK_STATS};
+use gym_rs_amd::ffi::{GYMRS_AUTO_RESET, GYMRS_TRACK_STATS};
 use rand::{thread_rng, Rng};
 
 fn main() {
