@@ -4,11 +4,11 @@
 //! reference's own `CartPoleEnv::step` / `MountainCarEnv::step` (cartpole.rs:398-483, mountain_car.rs:398-435), and
 //! writes files with the same schema whose OUTPUT fields (`next`, `reward`, `done`, `steps`, `final`, `total_reward`,
 //! `rewards`, `dones`) come from the reference.  Plus `reset_kat.json`: the states `reset(Some(seed))` gives for a few
-//! seeds (PCG64 + rand's Uniform: cartpole.rs:485-516, seeding.rs:21-26) -- reference data the Philox build does not
-//! reproduce by design, recorded for whoever wants the optional PCG64-compatible mode.
+//! seeds (PCG64 + rand's Uniform: cartpole.rs:485-516, seeding.rs:21-26) -- what the optional PCG64 reset mode
+//! (`gymrs_reset_pcg64`) reproduces; the default reset draws from Philox by design.
 //!
 //!     cargo run --release --bin make_golden -- ../../tests/golden ../../tests/golden/from_reference
-//!     python -m pytest tests/test_oracle_golden.py        # compares the C oracle with from_reference/ when present
+//!     python -m pytest tests/test_oracle_reference_pins.py tests/test_pcg64_reset.py   # hold the C oracle to from_reference/
 //!
 //! The image this repository is built in has no cargo/rustc, so this file has never been compiled there; it uses only
 //! the crate's public API (pub fields `state`, `kinematics_integrator`; `Env::step`; `Env::reset`).
