@@ -466,7 +466,7 @@ def run_rank(args, info, backend, make_collective=None):
                 # observation column aliases the state column
                 roof["achieved_moved"] = traffic / (launch_us * 1e-6) / 1e9
                 roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
-            if not args.no_probe and hasattr(backend, "copy_probe"):
+            if not args.no_probe and info.world == 1 and hasattr(backend, "copy_probe"):  # (a one-GPU diagnostic: no rank keeps the others waiting)
                 # the same box, the same process: what a plain copy gets (a) on HBM, (b) at this launch's footprint
                 nt = 1 if n * bytes_per_step <= (48 << 20) else 0
                 big = 1 << 30
@@ -514,6 +514,7 @@ def run_rank(args, info, backend, make_collective=None):
         elif info.world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
     eng.close()
+    coll.barrier()  # every rank leaves the process group together
     coll.close()
     return out
 
