@@ -145,3 +145,13 @@ def test_full_size_pcg64_reset(gymrs, oracle):
         assert a.min() >= np.float32(-0.05) and a.max() <= np.float32(0.05)
         assert abs(float(a.mean())) < 2e-4 and abs(float(a.std()) - 0.1 / np.sqrt(12)) < 2e-4
         assert abs(np.corrcoef(a)[0, 1]) < 5e-3  # x and x_dot of one lane come from consecutive outputs of one generator
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 65, 1000])
+def test_pcg64_reset_ragged_sizes(gymrs, oracle, n):
+    """Lane counts that are no multiple of anything, incl. engines whose arrays live in mapped host memory (n <= 64)."""
+    for kind in (0, 1):
+        with gymrs.BatchedEngine(kind, n, flags=0, global_env_offset=3) as eng:
+            eng.reset_pcg64(11)
+            want = want_states(oracle, kind, [11 + 3 + i for i in range(n)])
+            assert np.array_equal(eng.get_state().view(np.uint32), want.view(np.uint32))

@@ -177,3 +177,21 @@ def test_full_size_long_run_statistics(gymrs):
     assert json.loads(a.env_json(0))["gymrs"]["time_limit_elided_launches"] >= steps - 8
     a.close()
     b.close()
+
+
+def test_elision_on_a_callers_stream_and_on_one_lane(gymrs, twin):
+    """The refresh kernels follow the engine onto an external stream (gymrs_set_stream); a one-lane engine (arrays in
+    mapped host memory) elides and truncates like any other."""
+    import ctypes as C
+
+    p = Pair(gymrs, twin, 0, 3000, limit=30, seed=2)
+    s = torch.cuda.Stream()
+    lib = gymrs.load_library()
+    assert lib.gymrs_set_stream(p.eng._h, C.c_void_p(s.cuda_stream)) == 0
+    with torch.cuda.stream(s):
+        p.step(150, check_flags=True)
+    p.check("on the caller's stream")
+    assert 0 < p.elided() < p.t
+    one = Pair(gymrs, twin, 0, 1, limit=12, seed=4)
+    one.step(120, check_flags=True)
+    one.check("one lane")
