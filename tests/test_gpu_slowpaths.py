@@ -258,6 +258,14 @@ def test_small_engines_in_mapped_host_memory_match_large_ones(gymrs, kind):
     r.rollout(23, action_seed=4, action_t0=7)
     same(r, large)
     assert np.array_equal(small.stats()[1:], c_small.stats()[1:])
+    if not (kind == 2):  # captured graphs on the mapped-memory engine (Pendulum with the time limit has no graph mode)
+        ring = torch.zeros((8, 65), dtype=torch.uint8, device="cuda:0")
+        for b in range(8):
+            large.fill_actions(ring[b].data_ptr(), seed=6, t=b)
+        small_ring = ring[:, :64].contiguous()
+        small.step_many(small_ring.data_ptr(), 64, 8, 80, use_graph=True)
+        large.step_many(ring.data_ptr(), 65, 8, 80, use_graph=True)
+        same(small, large)
     if kind != 2:  # an invalid action is still reported (through the mapped error flag)
         bad = np.zeros(64, dtype)
         bad[3] = 7
