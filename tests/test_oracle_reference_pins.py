@@ -102,3 +102,43 @@ def test_oracle_against_fixtures_generated_by_the_reference(oracle):
             if r.done:
                 break
         assert t == tr["steps"]
+
+
+def test_default_constants_against_the_reference_source_text(oracle):
+    """Where /root/reference is present (the authoring container; not the GPU box): the `let name = OrderedFloat(value);`
+    lines of CartPoleEnv::new / MountainCarEnv::new (cartpole.rs:94-103, mountain_car.rs:344-351), the default reset boxes
+    (cartpole.rs:353-360, mountain_car.rs:175-186) and the action-space sizes are read as DATA and compared with the oracle's
+    and the product header's defaults.  No reference code is executed or copied."""
+    import math
+    import re
+    from pathlib import Path
+
+    import pytest
+
+    src = Path("/root/reference/src/envs/classical_control")
+    if not (src / "cartpole.rs").exists():
+        pytest.skip("/root/reference is not on this box")
+
+    def lets(text):
+        out = {}
+        for name, expr in re.findall(r"let (\w+) = OrderedFloat\(([^;]+)\);", text):
+            expr = expr.strip().replace("PI", str(math.pi))
+            if re.fullmatch(r"[-0-9. */]+", expr):
+                out.setdefault(name, eval(expr))  # noqa: S307 (digits and arithmetic operators only)
+        return out
+
+    cp_text, mc_text = (src / "cartpole.rs").read_text(), (src / "mountain_car.rs").read_text()
+    cp, mc = lets(cp_text), lets(mc_text)
+    p = oracle.cartpole_params()
+    for name in ("gravity", "masscart", "masspole", "length", "force_mag", "tau", "theta_threshold_radians", "x_threshold"):
+        assert getattr(p, name) == cp[name], name
+    q = oracle.mountain_car_params()
+    for name in ("min_position", "max_position", "max_speed", "goal_position", "goal_velocity", "force", "gravity"):
+        assert getattr(q, name) == mc[name], name
+    assert re.search(r"let action_space = Discrete\(2\);", cp_text) and re.search(r"Discrete\(3\)", mc_text)
+    # default reset boxes: +-0.05 on every CartPole component, position in [-0.6, -0.4) for MountainCar
+    assert cp_text.count("OrderedFloat(0.05)") == 4
+    assert "position: OrderedFloat(-0.6)" in mc_text and "position: OrderedFloat(-0.4)" in mc_text
+    assert all(-0.05 <= v < 0.05 for v in oracle.reset_pcg64(0, 1)) and -0.6 <= oracle.reset_pcg64(1, 1)[0] < -0.4
+    # the quirk the build keeps (SURVEY Q1): polemass_length = masspole + length
+    assert re.search(r"fn polemass_length[^}]*self\.masspole \+ self\.length", cp_text, re.S)
