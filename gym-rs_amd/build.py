@@ -23,15 +23,9 @@ ORACLE = ROOT / "oracle"
 
 HIP_SOURCES = [CSRC / "gymrs_step_cartpole.hip", CSRC / "gymrs_step_mountain_car.hip", CSRC / "gymrs_step_pendulum.hip",
                CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip"]
-HIP_HEADERS = [
-    CSRC / "gymrs_kernels.h",
-    CSRC / "gymrs_step_impl.h",
-    CSRC / "gymrs_tile.h",
-    CSRC / "gymrs_physics.h",
-    CSRC / "gymrs_philox.h",
-    CSRC / "gymrs_math.h",
-    ROOT / "include" / "gymrs_amd.h",
-]
+# every header of the kernel library: the same glob bench.kernel_source_sha16() hashes (a hand-kept
+# list had missed gymrs_json.h and gymrs_pcg64.h, so editing them did not rebuild the library)
+HIP_HEADERS = sorted(CSRC.glob("gymrs_*.h")) + [ROOT / "include" / "gymrs_amd.h"]
 LIB = PKG / "libgymrs_amd.so"
 
 # -ffp-contract=off: the shared physics header spells out every fma; nothing else may be fused,

@@ -14,29 +14,44 @@
 namespace gymrs {
 namespace json {
 
-// serde_json prints an f64 with ryu: the shortest digits that parse back to the same double; "1.0" for integral
-// values; exponent form without '+' or leading zeros ("1e-7", "1e16"); NaN and infinities become null.
+// serde_json prints an f64 with ryu's "pretty" layout (the `ryu` crate, src/pretty/mod.rs; recalled, the crate is not in this
+// image): the shortest digit string d1..dn that parses back to the same double, value = 0.d1..dn x 10^kk, laid out as
+//   0 <= kk - n and kk <= 16    digits, zeros, ".0"        10.0, 200.0, 100000.0, 1000000000000000.0
+//   0 < kk <= 16                point inside               9.8, 0.5 is the next case, 12.34
+//   -5 < kk <= 0                "0." zeros digits          0.02, 0.0025, 0.00001234
+//   otherwise                   d1[.d2..dn]e(kk-1)         1e16, 1.5e-7, 1e-6   (no '+', no leading zeros)
+// NaN and the infinities become null (serde_json's to_string).
 inline std::string number(double v)
 {
     if (!std::isfinite(v)) return "null";
-    char buf[40];
-    for (int prec = 1; prec <= 17; ++prec) {
-        std::snprintf(buf, sizeof(buf), "%.*g", prec, v);
+    if (v == 0.0) return std::signbit(v) ? "-0.0" : "0.0";
+    char buf[48];
+    for (int prec = 0; prec <= 16; ++prec) { // shortest "%.{prec}e" that round-trips
+        std::snprintf(buf, sizeof(buf), "%.*e", prec, v);
         if (std::strtod(buf, nullptr) == v) break;
     }
-    std::string s(buf);
-    const size_t e = s.find('e');
-    if (e != std::string::npos) { // "1e-07" -> "1e-7", "1e+16" -> "1e16"
-        std::string mant = s.substr(0, e), ex = s.substr(e + 1);
-        bool neg = false;
-        size_t i = 0;
-        if (i < ex.size() && (ex[i] == '+' || ex[i] == '-')) neg = ex[i++] == '-';
-        while (i + 1 < ex.size() && ex[i] == '0') ++i;
-        s = mant + "e" + (neg ? "-" : "") + ex.substr(i);
-    } else if (s.find('.') == std::string::npos) {
-        s += ".0";
+    std::string digits;
+    const char* p = buf;
+    const bool neg = *p == '-';
+    if (neg) ++p;
+    for (; *p && *p != 'e'; ++p)
+        if (*p != '.') digits += *p;
+    const int exp10 = std::atoi(p + 1);                  // value = d1.d2..dn x 10^exp10
+    while (digits.size() > 1 && digits.back() == '0') digits.pop_back();
+    const int n = (int)digits.size(), kk = exp10 + 1;    // value = 0.d1..dn x 10^kk
+    std::string out = neg ? "-" : "";
+    if (kk >= n && kk <= 16) {
+        out += digits + std::string((size_t)(kk - n), '0') + ".0";
+    } else if (kk > 0 && kk <= 16) {
+        out += digits.substr(0, (size_t)kk) + "." + digits.substr((size_t)kk);
+    } else if (kk > -5 && kk <= 0) {
+        out += "0." + std::string((size_t)(-kk), '0') + digits;
+    } else {
+        out += digits.substr(0, 1);
+        if (n > 1) out += "." + digits.substr(1);
+        out += "e" + std::to_string(kk - 1);
     }
-    return s;
+    return out;
 }
 
 inline std::string quoted(const char* text)

@@ -38,6 +38,25 @@ GYMRS_HD float clipf(float v, float l, float r)
 // tests/test_twin_vs_oracle.py and on the GPU), and gfx950 and x86 execute the identical operations, so the GPU stays
 // bit-identical to its CPU twin.  The f64 oracle (oracle/gymrs_oracle.c) keeps the reference's exact operation order.
 
+// Thresholds the reference compares an f64 state against (cartpole.rs:450-453 `x > x_threshold`, mountain_car.rs:422
+// `position >= goal_position`), restated for an f32 state so that the FLAG is exact: for every f32 v,
+//   v > t  (f64)  <=>  v > f32_not_above(t)        v >= t  (f64)  <=>  v >= f32_not_below(t)
+// (round-to-nearest would put fl32(2.4) = 2.4000001 above 2.4 and keep a lane sitting on 2.4000001 alive where the
+// reference ends it).  With these, done/terminated on identical f32 inputs equals the reference's f64 compare bit for bit;
+// only the f32-vs-f64 error of the STATE remains.
+inline float f32_not_above(double t)
+{
+    float f = (float)t;
+    if ((double)f > t) f = __builtin_nextafterf(f, -__builtin_inff());
+    return f;
+}
+inline float f32_not_below(double t)
+{
+    float f = (float)t;
+    if ((double)f < t) f = __builtin_nextafterf(f, __builtin_inff());
+    return f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // CartPole
 struct CartPoleConsts {
@@ -47,7 +66,7 @@ struct CartPoleConsts {
                            // and total_mass = masspole + masscart (cartpole.rs:146-148)
     float len_43;          // length * (4.0/3.0)                          cartpole.rs:427
     float len_mp_over_tm;  // length * masspole / total_mass              cartpole.rs:427-428
-    float theta_thr, x_thr;
+    float theta_thr, x_thr; // largest f32 <= the f64 thresholds (f32_not_above): `|v| > thr` is then the reference's compare
     int32_t integrator;    // 0 Euler, 1 Other             cartpole.rs:380-387
     uint32_t max_steps;
 };
@@ -63,8 +82,8 @@ inline CartPoleConsts make_consts(const gymrs_cartpole_params& p)
     c.pml_over_tm = (float)(polemass_length / total_mass);
     c.len_43 = (float)(p.length * (4.0 / 3.0));
     c.len_mp_over_tm = (float)(p.length * p.masspole / total_mass);
-    c.theta_thr = (float)p.theta_threshold_radians;
-    c.x_thr = (float)p.x_threshold;
+    c.theta_thr = f32_not_above(p.theta_threshold_radians); // cartpole.rs:450-453: strict f64 compares of an f32 state
+    c.x_thr = f32_not_above(p.x_threshold);
     c.integrator = p.kinematics_integrator;
     c.max_steps = p.max_episode_steps ? p.max_episode_steps : 500u;
     return c;
@@ -136,8 +155,8 @@ inline MountainCarConsts make_consts(const gymrs_mountain_car_params& p)
     c.min_position = (float)p.min_position;
     c.max_position = (float)p.max_position;
     c.max_speed = (float)p.max_speed;
-    c.goal_position = (float)p.goal_position;
-    c.goal_velocity = (float)p.goal_velocity;
+    c.goal_position = f32_not_below(p.goal_position); // mountain_car.rs:422: inclusive f64 compares of an f32 state
+    c.goal_velocity = f32_not_below(p.goal_velocity);
     c.force = (float)p.force;
     c.gravity = (float)p.gravity;
     c.max_steps = p.max_episode_steps ? p.max_episode_steps : 200u;

@@ -196,3 +196,62 @@ def test_params_from_json_keeps_missing_keys_and_rejects_wrong_types(gymrs):
     for bad in ('{"gravity": "x"}', '{"gravity": 1,}', "", '{"kinematics_integrator": "RK4"}', '{"state": 3}'):
         with pytest.raises(gymrs.GymrsError):
             gymrs.params_from_json(gymrs.CARTPOLE, bad)
+
+
+def _ryu_layout(v: float) -> str:
+    """serde_json's f64 text (ryu pretty layout), modelled on Python's shortest round-trip digits."""
+    import math
+    if not math.isfinite(v):
+        return "null"
+    if v == 0:
+        return "-0.0" if math.copysign(1, v) < 0 else "0.0"
+    mant, exp = f"{v:.17e}".split("e")  # placeholder for the sign; digits come from repr
+    sign = "-" if v < 0 else ""
+    r = repr(abs(v))
+    if "e" in r:
+        m, e = r.split("e")
+        e = int(e)
+    else:
+        m, e = r, 0
+    ip, _, fp = m.partition(".")
+    digits = (ip + fp).lstrip("0")
+    kk = len(ip) + e if ip.strip("0") else e - (len(fp) - len(fp.lstrip("0")))
+    digits = digits.rstrip("0") or "0"
+    n = len(digits)
+    if n <= kk <= 16:
+        return sign + digits + "0" * (kk - n) + ".0"
+    if 0 < kk <= 16:
+        return sign + digits[:kk] + "." + digits[kk:]
+    if -5 < kk <= 0:
+        return sign + "0." + "0" * (-kk) + digits
+    return sign + digits[0] + ("." + digits[1:] if n > 1 else "") + "e" + str(kk - 1)
+
+
+def test_json_numbers_are_laid_out_like_serde_json(tmp_path):
+    """gymrs_json.h printed 10.0 as "1e1"; serde_json (ryu) prints plain decimals with a trailing ".0" for
+    decimal exponents in [-5, 16) and exponent form otherwise.  Text-level check of the header, against known serde_json outputs
+    and a Python model of the layout on random doubles."""
+    import random
+    import struct
+    known = {10.0: "10.0", 200.0: "200.0", 100000.0: "100000.0", 9.8: "9.8", 0.02: "0.02", 0.0025: "0.0025", 1e16: "1e16",
+             1e15: "1000000000000000.0", 1.5e-7: "1.5e-7", 1e-5: "0.00001", 1e-6: "1e-6", -2.4: "-2.4",
+             0.20943951023931953: "0.20943951023931953", 1e300: "1e300", 5e-324: "5e-324", 0.1: "0.1", 1.0: "1.0", 0.0: "0.0",
+             123456789012345678.0: "1.2345678901234568e17", 0.5: "0.5", 0.07: "0.07", -1.2: "-1.2", 0.001: "0.001"}
+    rnd = random.Random(5)
+    vals = list(known) + [struct.unpack("<d", struct.pack("<Q", rnd.getrandbits(64)))[0] for _ in range(3000)]
+    vals += [rnd.uniform(-100, 100) for _ in range(500)] + [float(rnd.randint(-10**17, 10**17)) for _ in range(500)]
+    vals = [v for v in vals if v == v and abs(v) != float("inf")]
+    src = tmp_path / "num.cpp"
+    src.write_text('#include "gymrs_json.h"\n#include <cstdio>\n#include <cstdlib>\nint main(int, char** a){ FILE* f = fopen(a[1], "rb"); double v; '
+                   'while (fread(&v, 8, 1, f) == 1) std::printf("%s\\n", gymrs::json::number(v).c_str()); return 0; }\n')
+    exe = tmp_path / "num"
+    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'gym-rs_amd' / 'csrc'}", str(src), "-o", str(exe)], check=True)
+    data = tmp_path / "vals.bin"
+    data.write_bytes(b"".join(struct.pack("<d", v) for v in vals))
+    out = subprocess.run([str(exe), str(data)], capture_output=True, text=True, check=True).stdout.split()
+    assert len(out) == len(vals)
+    for v, text in zip(vals, out):
+        assert float(text) == v, (v, text)           # round-trips
+        assert text == _ryu_layout(v), (v, text, _ryu_layout(v))
+        if v in known:
+            assert text == known[v], (v, text)

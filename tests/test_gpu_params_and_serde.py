@@ -92,6 +92,9 @@ def test_env_json_has_the_reference_fields_and_round_trips(gymrs):
     st[:, 3] = [0.25, -1.5, 0.03125, 2.0]
     eng.set_state(st)
     d = json.loads(eng.env_json(3))
+    # text level: serde_json prints 10.0 / 0.02 / 9.8, never "1e1"
+    text3 = eng.env_json(3)
+    assert '"force_mag":10.0' in text3 and '"tau":0.02' in text3 and '"masscart":1.0' in text3 and '"x_threshold":2.4' in text3
     # serde field order of cartpole.rs:52-87 (renderer/screen are GUI-only, rand_random is #[serde(skip_serializing)])
     assert list(d) == ["action_space", "observation_space", "render_mode", "state", "metadata", "gravity", "masscart", "masspole",
                        "length", "force_mag", "tau", "kinematics_integrator", "theta_threshold_radians", "x_threshold",

@@ -62,8 +62,13 @@ def test_cartpole_large_angles_and_non_finite_states(gymrs, twin, oracle, vec):
                 rows.append(((0.3, -0.7, sign * th, 0.9), a))
     rows += [((nan, 0.1, 0.01, 0.2), 0), ((0.1, 0.1, nan, 0.2), 1), ((inf, 0.1, 0.01, 0.2), 0), ((-inf, 0.1, 0.01, 0.2), 1),
              ((0.1, 0.1, inf, 0.2), 0), ((0.1, 0.1, -inf, 0.2), 1), ((0.1, nan, 0.01, 0.2), 0), ((0.1, 0.1, 0.01, inf), 1),
-             ((2.4, 0.0, 0.0, 0.0), 1), ((-2.4, 0.0, 0.0, 0.0), 0),  # exactly on the threshold: strict compares
-             ((0.0, 0.0, 0.20943951606750488, 0.0), 1), ((0.0, 0.0, 0.7853981, 3.0), 0), ((0.0, 0.0, 0.7853982, 3.0), 1)]
+             # around the thresholds (the velocities are 0, so the step leaves x / theta where they are): fl32(2.4) = 2.4000001 and
+             # fl32(theta_thr) = 0.20943952 lie ABOVE the f64 thresholds -> the reference ends these lanes (cartpole.rs:450-453);
+             # the largest f32 values below them (2.3999999, 0.2094395) stay alive: the compares are strict
+             ((2.4, 0.0, 0.0, 0.0), 1), ((-2.4, 0.0, 0.0, 0.0), 0), ((2.3999998569488525, 0.0, 0.0, 0.0), 1), ((-2.3999998569488525, 0.0, 0.0, 0.0), 0),
+             ((0.0, 0.0, 0.20943951606750488, 0.0), 1), ((0.0, 0.0, -0.20943951606750488, 0.0), 0),
+             ((0.0, 0.0, 0.20943950116634369, 0.0), 1), ((0.0, 0.0, -0.20943950116634369, 0.0), 0),
+             ((0.0, 0.0, 0.7853981, 3.0), 0), ((0.0, 0.0, 0.7853982, 3.0), 1)]
     # pad with ordinary lanes so that the special ones share wavefronts with common-path lanes (and with each other)
     rng = np.random.default_rng(1)
     while len(rows) < 300:
@@ -77,13 +82,23 @@ def test_cartpole_large_angles_and_non_finite_states(gymrs, twin, oracle, vec):
     ref = st.astype(np.float64).copy()
     ref_r, ref_d, bad = oracle.cartpole_step_batch(ref, np.zeros(len(rows), np.uint8), act)
     assert bad == 0
-    # f32 vs f64 may disagree on `done` only within 1e-5 of a threshold: the lanes placed exactly ON the f32
-    # thresholds (2.4f > 2.4) are such cases -- strict compares keep them alive in f32, the f64 oracle ends them
+    # The kernel compares against the largest f32 <= each f64 threshold (gymrs_physics.h f32_not_above), which for an f32
+    # state IS the reference's f64 compare: the flags agree on every lane, the ones placed one f32 step either side of the
+    # thresholds included (round 2 rounded the thresholds to nearest and tolerated 3 mismatches here).
+    assert np.array_equal(done, ref_d), np.nonzero(done != ref_d)
+    on = {2.4: 1, -2.4: 1, 2.3999998569488525: 0, -2.3999998569488525: 0}
+    for i, r in enumerate(rows):
+        if r[0][0] in on and r[0][1] == 0.0:
+            assert done[i] == on[r[0][0]], (i, r)
+        if r[0][3] == 0.0 and abs(r[0][2]) == 0.20943951606750488:
+            assert done[i] == 1, (i, r)
+        if r[0][3] == 0.0 and abs(r[0][2]) == 0.20943950116634369:
+            assert done[i] == 0, (i, r)
+    # and the flag equals the reference's f64 compares applied to the f32 state the kernel produced (no tolerance)
     with np.errstate(invalid="ignore"):
-        near = (np.abs(np.abs(ref[0]) - 2.4) < 1e-5) | (np.abs(np.abs(ref[2]) - 0.20943951023931953) < 1e-5)
-    mism = done != ref_d
-    assert near[mism].all() and mism.sum() <= 3, np.nonzero(mism)
-    assert not done[[i for i, r in enumerate(rows) if r[0][0] in (2.4, -2.4) and r[0][1] == 0.0]].any()  # `>` is strict
+        g64 = got.astype(np.float64)
+        want = ~(np.abs(g64[0]) <= 2.4) | ~(np.abs(g64[2]) <= 0.20943951023931953)
+    assert np.array_equal(done.astype(bool), want)
     assert close_or_same_special(got, ref).all(), np.nonzero(~close_or_same_special(got, ref))
     assert np.array_equal(reward, ref_r.astype(np.float32))
     # Q10: a NaN anywhere in x or theta terminates; every large angle terminates

@@ -182,3 +182,53 @@ def test_time_limit_truncation_twin(twin, gymrs):
         assert tr.all() == ((t + 1) % 7 == 0) and tr.any() == ((t + 1) % 7 == 0)
     s = te.stats()
     assert s[2] == 64 * 3 and s[1] == 64 * 21 and s[0] == -64 * 21
+
+
+def _f64_flags_of_f32_state(kind, st32, P):
+    """The reference's own termination compares (f64) applied to an f32 state: cartpole.rs:450-453, mountain_car.rs:422."""
+    s = st32.astype(np.float64)
+    with np.errstate(invalid="ignore"):
+        if kind == 0:  # strict; a NaN is the maximum in OrderedFloat's order, hence "not <="
+            return ~(np.abs(s[0]) <= P.x_threshold) | ~(np.abs(s[2]) <= P.theta_threshold_radians)
+        return ~(s[0] < P.goal_position) & ~(s[1] < P.goal_velocity)  # inclusive
+
+
+@pytest.mark.parametrize("kind,tweak", [(0, {}), (0, {"x_threshold": 1.0 / 3.0, "theta_threshold_radians": 0.1}),
+                                        (1, {}), (1, {"goal_position": 0.1, "goal_velocity": 1e-3})])
+def test_done_flag_is_the_f64_compare_of_the_f32_state(kind, tweak, twin, gymrs):
+    """the kernels keep their thresholds as the largest f32 <= (smallest f32 >=) the f64 value, so that
+    for the f32 state they hold the flag IS the reference's f64 compare -- checked with NO tolerance band, on states spread
+    over the thresholds and on the f32 neighbours of every threshold."""
+    n = 400_000
+    rng = np.random.default_rng(50 + kind)
+    P = gymrs.engine.default_params(kind)
+    for k, v in tweak.items():
+        setattr(P, k, v)
+    te = TwinEngine(twin, kind, n, P, flags=0)
+    te.reset(1)
+    if kind == 0:
+        xt, tt = P.x_threshold, P.theta_threshold_radians
+        st = np.stack([rng.uniform(-1.02 * xt, 1.02 * xt, n), rng.uniform(-0.5, 0.5, n), rng.uniform(-1.02 * tt, 1.02 * tt, n),
+                       rng.uniform(-0.5, 0.5, n)]).astype(np.float32)
+        # lanes that sit still on the f32 neighbours of +-threshold (zero velocities keep x and theta where they are)
+        edge = []
+        for thr, row in ((xt, 0), (tt, 2)):
+            f = np.float32(thr)
+            for v in (f, np.nextafter(f, np.float32(0)), np.nextafter(f, np.float32(9))):
+                for sgn in (1, -1):
+                    e = np.zeros(4, np.float32)
+                    e[row] = sgn * v
+                    edge.append(e)
+        st[:, : len(edge)] = np.array(edge).T
+        act = rng.integers(0, 2, n).astype(np.uint8)
+    else:
+        gp, gv = P.goal_position, P.goal_velocity
+        st = np.stack([rng.uniform(gp - 0.05, gp + 0.05, n), rng.uniform(gv - 0.01, gv + 0.01, n)]).astype(np.float32)
+        act = rng.integers(0, 3, n).astype(np.uint8)
+    te.set_state(st)
+    te.step(act)
+    _, done, _ = te.get_result()
+    after = te.get_state()
+    want = _f64_flags_of_f32_state(kind, after, P)
+    assert 0.02 < want.mean() < 0.98  # the sample straddles the thresholds
+    assert np.array_equal(done.astype(bool), want), np.nonzero(done.astype(bool) != want)[0][:10]
