@@ -141,6 +141,7 @@ struct gymrs_engine {
     uint32_t* age_host_dev = nullptr;   // the device's address of it
     uint32_t age_seq = 0;               // sequence number of the refresh in flight
     bool age_pending = false;
+    bool age_gave_up = false;           // a bounded wait for the refresh in flight ran out: do not wait for THIS refresh again
     bool age_near_done = false;         // the one refresh of this approach to the limit has been issued
     bool last_elided = false;           // the previous per-step launch ran without the limit
     uint64_t age_ref_tick = 0;          // tick the ages of the refresh in flight are measured from
@@ -158,6 +159,22 @@ static RcclApi g_rccl;
 // take-over uses plain, allocating accesses once.  (Periodically doing so for one engine costs more than it brings.)
 constexpr int kMaxDevices = 64;
 static std::atomic<const gymrs_engine*> g_last_stepper[kMaxDevices];
+// Consecutive per-step launches of g_last_stepper: the plain "install" launch is only worth it when the other engine ran long
+// enough to have pushed this one's arrays out of the cache.  Engines stepped alternately (train + eval, several shards
+// per GPU) keep their hints (they used to lose the non-temporal hint on EVERY launch).
+static std::atomic<uint32_t> g_stepper_run[kMaxDevices];
+constexpr uint32_t kTakeOverAfter = 64;
+
+// What the reference's TYPES rule out (everything else is a `pub` f64 field the reference accepts as it is, NaN included):
+// KinematicsIntegrator is a two-variant enum (cartpole.rs:380-387).
+static gymrs_status check_params(gymrs_env_kind kind, const void* params, const char* who)
+{
+    if (kind == GYMRS_CARTPOLE && params) {
+        const int k = static_cast<const gymrs_cartpole_params*>(params)->kinematics_integrator;
+        if (k != 0 && k != 1) return fail(GYMRS_EINVAL, std::string(who) + ": kinematics_integrator must be 0 (Euler) or 1 (Other)");
+    }
+    return GYMRS_OK;
+}
 
 static const void* consts_ptr(const gymrs_engine* e)
 {
@@ -309,27 +326,54 @@ static void limit_restart(gymrs_engine* e, uint64_t bound, bool trunc_zero)
     e->start_bound = bound;
     e->trunc_zero = trunc_zero;
     e->age_pending = false; // a refresh still in flight measured another episode clock: its result is never adopted
+    e->age_gave_up = false;
     e->age_near_done = false;
     e->last_elided = false;
     e->age_next_refresh = 0;
     e->age_backoff = 8;
 }
 
-// Wait until the refresh in flight has published its result (mapped host memory; the device writes the age, then the
-// sequence number).  A caller that waits for every step finds it there; one that queues launches far ahead of the GPU
-// waits here until the GPU has caught up with the refresh.
-static gymrs_status wait_for_age(gymrs_engine* e)
+// Wait -- for a BOUNDED time -- until the refresh in flight has published its result (mapped host memory; the device writes
+// the age, then the sequence number).  A caller that waits for every step finds it there; one that queues launches far
+// ahead of the GPU waits here until the GPU has caught up with the refresh, which caps its lead.  *arrived = false when the
+// answer is not there after kAgeWaitNs: the caller then launches the kernel WITH the limit, which is always correct
+// (a caller-provided stream may be blocked on work this very thread has not submitted yet -- an event it
+// records later, a capture -- and an unbounded spin would never end).
+constexpr uint64_t kAgeWaitNs = 2'000'000; // ~300 launches of the headline kernel
+static gymrs_status wait_for_age(gymrs_engine* e, bool* arrived)
 {
+    const auto t0 = std::chrono::steady_clock::now();
+    *arrived = true;
     for (uint64_t spins = 0; e->age_host[1] != e->age_seq; ++spins) {
-        if ((spins & 0xfffu) == 0xfffu) { // every few microseconds: is the stream still alive?
+        if ((spins & 0xfffu) == 0xfffu) { // every few microseconds: is the stream still alive, is there time left?
             const hipError_t q = hipStreamQuery(e->stream);
             if (q != hipSuccess && q != hipErrorNotReady) return fail(GYMRS_EHIP, std::string("time-limit refresh: ") + hipGetErrorString(q));
             if (q == hipSuccess && e->age_host[1] != e->age_seq)
                 return fail(GYMRS_EHIP, "time-limit refresh: the stream is idle but the result never arrived");
+            if ((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kAgeWaitNs) {
+                *arrived = false;
+                return GYMRS_OK;
+            }
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
     return GYMRS_OK;
+}
+
+// The elision is off when GYMRS_NO_LIMIT_ELISION=1 is in the environment (every launch checks the limit, as in round 1), and
+// for launches into a stream that is being captured (what is baked into a graph cannot follow start_bound).
+static bool elision_disabled(const gymrs_engine* e)
+{
+    static const bool off = [] {
+        const char* v = std::getenv("GYMRS_NO_LIMIT_ELISION");
+        return v && v[0] == '1';
+    }();
+    if (off) return true;
+    if (!e->own_stream) { // only a caller-provided stream can be under a capture this library did not start
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(e->stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return true;
+    }
+    return false;
 }
 
 // The flags of ONE per-step launch at the engine's current tick.  A step takes a lane to the limit iff
@@ -345,14 +389,28 @@ static gymrs_status wait_for_age(gymrs_engine* e)
 static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
 {
     uint32_t flags = launch_flags_of(e);
-    if (e->device >= 0 && e->device < kMaxDevices && g_last_stepper[e->device].exchange(e, std::memory_order_relaxed) != e && e->nt_mode == 0)
-        flags &= ~kFlagNonTemporal; // taking over the device from another engine (or first launch): install the lines, see above
+    if (e->device >= 0 && e->device < kMaxDevices) {
+        const gymrs_engine* prev = g_last_stepper[e->device].exchange(e, std::memory_order_relaxed);
+        if (prev == e) {
+            g_stepper_run[e->device].fetch_add(1, std::memory_order_relaxed);
+        } else {
+            const uint32_t run = g_stepper_run[e->device].exchange(1, std::memory_order_relaxed);
+            // taking over the device from an engine that ran for a while (or first launch): install the lines, see above
+            if ((prev == nullptr || run >= kTakeOverAfter) && e->nt_mode == 0) flags &= ~kFlagNonTemporal;
+        }
+    }
     *out = flags;
     if (!e->limit_elidable) return GYMRS_OK;
+    if (elision_disabled(e)) {
+        e->trunc_zero = false;
+        e->last_elided = false;
+        return GYMRS_OK;
+    }
     const uint64_t limit = limit_of(e);
     const uint64_t margin = limit / 4 < 16 ? limit / 4 : 16;
     auto adopt = [e]() {
         e->age_pending = false;
+        e->age_gave_up = false;
         const uint64_t bound = e->age_ref_tick - (uint64_t)e->age_host[0];
         if (bound > e->start_bound) e->start_bound = bound;
     };
@@ -360,12 +418,14 @@ static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
         std::atomic_thread_fence(std::memory_order_acquire);
         adopt();
     }
-    if (e->age_pending && e->tick + 1 - e->start_bound >= limit) { // the answer decides THIS launch
+    if (e->age_pending && !e->age_gave_up && e->tick + 1 - e->start_bound >= limit) { // the answer decides THIS launch
         const auto t0 = std::chrono::steady_clock::now();
-        if (gymrs_status st = wait_for_age(e)) return st;
+        bool arrived = false;
+        if (gymrs_status st = wait_for_age(e, &arrived)) return st;
         e->age_waits += 1;
         e->age_wait_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-        adopt();
+        if (arrived) adopt();
+        else e->age_gave_up = true; // the bound stays stale, `reachable` below is true and this launch checks the limit itself
     }
     const uint64_t oldest = e->tick + 1 - e->start_bound; // no episode is older than this after the step
     const bool reachable = oldest >= limit, near = oldest + margin >= limit;
@@ -581,6 +641,7 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     *out = nullptr;
     if (kind != GYMRS_CARTPOLE && kind != GYMRS_MOUNTAIN_CAR && kind != GYMRS_PENDULUM)
         return fail(GYMRS_EINVAL, "gymrs_engine_create: unknown env kind");
+    if (gymrs_status st = check_params(kind, params, "gymrs_engine_create")) return st;
     if (n_envs == 0) return fail(GYMRS_EINVAL, "gymrs_engine_create: n_envs must be > 0");
     if (n_envs > (1ull << 32)) return fail(GYMRS_EINVAL, "gymrs_engine_create: n_envs must be <= 2^32 per engine");
     if (flags & ~(uint32_t)(GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT))
@@ -1178,7 +1239,10 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
             HIP_TRY(hipMemcpyAsync(e->tick_dev, &tick_now, sizeof(tick_now), hipMemcpyHostToDevice, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream)); // tick_now is a stack variable; the copy must finish before return
             if (gymrs_status st = fold_reset_log(e)) return st; // the captured fold steps assume an empty ring at the start
-            if (e->device >= 0 && e->device < kMaxDevices) g_last_stepper[e->device].store(e, std::memory_order_relaxed);
+            if (e->device >= 0 && e->device < kMaxDevices) {
+                g_last_stepper[e->device].store(e, std::memory_order_relaxed);
+                g_stepper_run[e->device].store(kTakeOverAfter, std::memory_order_relaxed); // a replay is many launches
+            }
             while (n_steps - done >= per_graph) {
                 HIP_TRY(hipGraphLaunch(e->graph_exec, e->stream));
                 done += per_graph;
@@ -1281,6 +1345,11 @@ gymrs_status gymrs_get_obs(gymrs_engine* e, uint64_t first, uint64_t count, floa
     float* ptrs[4];
     int dim = 0;
     gymrs_obs_ptrs(e, ptrs, &dim);
+    if (e->pool_host) { // small engine: the arrays ARE host memory (no copy-engine command on the single-env mirror path)
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int j = 0; j < dim; ++j) std::memcpy(host_out + (size_t)j * count, host_of(e, ptrs[j]) + first, count * sizeof(float));
+        return GYMRS_OK;
+    }
     for (int j = 0; j < dim; ++j)
         HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, ptrs[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1662,6 +1731,7 @@ gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t see
 gymrs_status gymrs_set_params(gymrs_engine* e, const void* params)
 {
     if (!e || !params) return fail(GYMRS_EINVAL, "gymrs_set_params: NULL argument");
+    if (gymrs_status st = check_params(e->kind, params, "gymrs_set_params")) return st;
     switch (e->kind) {
     case GYMRS_CARTPOLE:
         e->params.cp = *static_cast<const gymrs_cartpole_params*>(params);
@@ -1729,9 +1799,15 @@ gymrs_status gymrs_env_json(gymrs_engine* e, uint64_t lane, char* buf, uint64_t 
     HIP_TRY(hipSetDevice(e->device));
     float st[4] = {0, 0, 0, 0};
     uint8_t beyond = 0;
-    for (int j = 0; j < e->state_dim; ++j) HIP_TRY(hipMemcpyAsync(&st[j], e->s[j] + lane, sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    if (e->kind == GYMRS_CARTPOLE) HIP_TRY(hipMemcpyAsync(&beyond, e->beyond + lane, 1, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->pool_host) { // small engine: plain loads from the mapped pool
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int j = 0; j < e->state_dim; ++j) st[j] = host_of(e, e->s[j])[lane];
+        if (e->kind == GYMRS_CARTPOLE) beyond = host_of(e, e->beyond)[lane];
+    } else {
+        for (int j = 0; j < e->state_dim; ++j) HIP_TRY(hipMemcpyAsync(&st[j], e->s[j] + lane, sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        if (e->kind == GYMRS_CARTPOLE) HIP_TRY(hipMemcpyAsync(&beyond, e->beyond + lane, 1, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     double low[4], high[4];
     int dim = 0;
     json::Object o;

@@ -148,7 +148,12 @@ gymrs_status gymrs_reset(gymrs_engine* e, int has_seed, uint64_t seed, const flo
  * CartPole and MountainCar only (the reference has no Pendulum): GYMRS_EINVAL otherwise.  Everything else -- cleared
  * flags, statistics, the seed echo, the Philox key of later GYMRS_AUTO_RESET re-arms -- is as for gymrs_reset.
  * The third-party algorithms (rand 0.8, rand_pcg 0.3, rand_core 0.6) are restated from their publications and pinned
- * by rand_pcg's own known answers (tests/golden/pcg64.json); SURVEY App. B.2. */
+ * by rand_pcg's own known answers (tests/golden/pcg64.json); SURVEY App. B.2.
+ * Rounding: the reference's f64 draw lies in [low, high); this call stores its NEAREST f32, so that a caller comparing start
+ * states with gym-rs sees every component within half an f32 ulp of the reference's.  The stored value therefore lies in the
+ * CLOSED f32 box [fl32(low), fl32(high)]: a draw within half an ulp of `high` rounds onto fl32(high) (probability ~2^-25 per
+ * draw), which may exceed `high` itself (fl32(0.05) > 0.05).  gymrs_reset (Philox) keeps its samples strictly below
+ * fl32(high); later GYMRS_AUTO_RESET re-arms of an engine reset through this call use that half-open f32 box. */
 gymrs_status gymrs_reset_pcg64(gymrs_engine* e, int has_seed, uint64_t seed, const uint64_t* seeds_dev,
                                const double* bounds_low_high, uint64_t* seed_used);
 
