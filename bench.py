@@ -12,8 +12,9 @@ at 2^20 parallel envs, f32.  At N>1 every rank holds 2^20 lanes (weak scaling; c
 path is one RCCL all-reduce of the 4 statistics doubles, taken AFTER the timed region (its cost is
 reported separately as stats_readout_us).
 
-Timing (">= 5 repetitions, report the median"): after W warm-up steps the bench times R = 5
-repetitions.  One repetition = P back-to-back passes of EXACTLY K steps, bracketed by
+Timing (">= 5 repetitions, report the median"): after W warm-up steps and ~60 ms of untimed stepping (the
+settle phase: a fresh process steps faster for its first ~20 ms than it does in the long run) the bench times R = 9
+repetitions and prints their min / median / max.  One repetition = P back-to-back passes of EXACTLY K steps, bracketed by
 barrier + torch.cuda.synchronize() on both sides (wall clock) and by HIP events on the engine's stream
 (kernel time); P is chosen once so that a repetition lasts >= ~5 ms -- K = 20 launches of a 7 us kernel
 are 0.14 ms, less than the host's own synchronisation jitter.  Per repetition the MAX over ranks is taken,
@@ -52,7 +53,20 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "
 # VALU issue roofline of the fused rollout kernel: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
 MIN_REPETITION_SECONDS = 5e-3
-REPETITIONS = 5
+REPETITIONS = 9
+# Untimed stepping between the warm-up and the first timed repetition.  A process that has just started steps FASTER for its
+# first ~20 ms than it does in the long run (profiles/r03_slow_mode.log: 6.31 us per step 15 ms in, 6.46 from ~40 ms on, on
+# the same box; the memory side relaxes -- the same-footprint copy probe goes 5.1 -> 5.6 us while the shader clock and a
+# VALU-only kernel do not move), so a bench that times 25 ms right after a 25-step warm-up reports a drifting transient
+# (round 2's driver record: 6.43 -> 6.96 us over its 5 repetitions).  The sustained rate is the honest one.
+SETTLE_SECONDS = 60e-3
+# The other BASELINE.json configs, measured by the default N=1 run after the headline and attached as `configs`
+# (VERDICT r2 "next" #3): name -> (env, lanes, action buffers)
+EXTRA_CONFIGS = {
+    "mountain_car_2p20": ("mountain_car", 1 << 20, 32),
+    "pendulum_2p22": ("pendulum", 1 << 22, 8),
+    "cartpole_2p24_dram_resident": ("cartpole", 1 << 24, 8),
+}
 
 
 def kernel_source_sha16() -> str:
@@ -132,6 +146,9 @@ def parse_args(argv=None):
     ap.add_argument("--native-rccl", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--repetitions", type=int, default=REPETITIONS)
     ap.add_argument("--no-probe", action="store_true", help="skip the in-process copy-kernel probe (roofline.peak_measured)")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the short legs for the other BASELINE configs (MountainCar 2^20, Pendulum 2^22, CartPole 2^24) that "
+                         "the default N=1 CartPole run attaches as `configs`")
     ap.add_argument("--pmc-traffic", action="store_true",
                     help="N=1: also run two short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) and "
                          "report the traffic they measure (and refresh profiles/pmc_traffic.json)")
@@ -167,6 +184,10 @@ class HipBackend:
     def make_engine(self, kind, n, offset, flags, vec):
         return self.gymrs.BatchedEngine(kind, n, global_env_offset=offset, device=self.dev_index, flags=flags,
                                         lanes_per_thread=vec or None)
+
+    def probe_engine(self, kind, offset, flags):
+        """A throw-away engine (own stream) for the first contact with RCCL: sharded.ShardedRun.setup_stats_allreduce."""
+        return self.make_engine(kind, 256, offset, flags, 0)
 
     def make_action_ring(self, eng, n, nbuf, is_float):
         torch = self.torch
@@ -218,7 +239,7 @@ def choose_passes(seconds_per_pass: float, min_seconds: float = MIN_REPETITION_S
 
 def timed_repetitions(backend, coll, stream, run_pass, passes, repetitions):
     """R repetitions of `passes` x run_pass(); per repetition the MAX over ranks of (wall seconds, event ms)."""
-    walls, kernels = [], []
+    walls, kernels, own = [], [], []
     for _ in range(repetitions):
         coll.barrier()
         backend.sync()
@@ -230,9 +251,12 @@ def timed_repetitions(backend, coll, stream, run_pass, passes, repetitions):
         backend.sync()
         t1 = time.perf_counter()
         coll.barrier()
-        wall, kms = coll.max([t1 - t0, backend.elapsed_ms(m0, m1)])
+        own_ms = backend.elapsed_ms(m0, m1)
+        wall, kms = coll.max([t1 - t0, own_ms])
         walls.append(wall)
         kernels.append(kms)
+        own.append(own_ms)
+    backend.own_event_ms = own  # this rank's own event times (the returned ones are the max over ranks)
     return walls, kernels
 
 
@@ -340,25 +364,31 @@ def run_rank(args, info, backend, make_collective=None):
     run_steps(args.warmup)
     eng.sync()
     # (an oversubscribed TEST run cannot use RCCL at all: it refuses two ranks on one device)
-    allreduce_path = run.setup_stats_allreduce(prefer_native=not (args.torch_allreduce or getattr(backend, "oversubscribed", False)))
+    allreduce_path = run.setup_stats_allreduce(
+        prefer_native=not (args.torch_allreduce or getattr(backend, "oversubscribed", False)),
+        # first contact with RCCL happens on a throw-away engine with its own stream (sharded.setup_stats_allreduce says why)
+        make_probe_engine=(lambda off: backend.probe_engine(kind, off, flags)) if hasattr(backend, "probe_engine") else None)
     if coll.active:
         run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
     backend.sync()
+    t_settle = time.perf_counter()
     t0 = time.perf_counter()
     run_steps(args.steps)  # first calibration pass: clocks may still be ramping up after a short warm-up
     backend.sync()
     first = time.perf_counter() - t0
-    again = min(choose_passes(first, 2e-3), 64)  # ~2 ms more, then the rate is the warm one
-    if os.environ.get("GYMRS_BENCH_PASSES"):      # tests pin the amount of work to compare two runs' statistics
-        again = 1
+    pinned = os.environ.get("GYMRS_BENCH_PASSES")  # tests pin the amount of work to compare two runs' statistics
+    # ~2 ms more for the rate, and in any case until the device has been stepping for SETTLE_SECONDS (see there)
+    again = max(choose_passes(first, 2e-3), choose_passes(first, SETTLE_SECONDS) - 1)
+    again = 1 if pinned else min(again, 4096)
     again = int(coll.max([again])[0])             # every rank steps the same number of times
     t0 = time.perf_counter()
     for _ in range(again):
         run_steps(args.steps)
     backend.sync()
     passes = choose_passes((time.perf_counter() - t0) / again)
-    if os.environ.get("GYMRS_BENCH_PASSES"):  # tests pin the amount of work to compare two runs' statistics
-        passes = max(1, int(os.environ["GYMRS_BENCH_PASSES"]))
+    settle_ms = (time.perf_counter() - t_settle) * 1e3
+    if pinned:
+        passes = max(1, int(pinned))
     passes = int(coll.max([passes])[0])  # every rank times the same work
     eng.stats_clear()
 
@@ -373,9 +403,12 @@ def run_rank(args, info, backend, make_collective=None):
     stats_readout_us = (time.perf_counter() - t0) * 1e6
     steps_per_lane = args.steps * passes * reps
     run.check_total_steps(total, steps_per_lane)
+    # (kernels = max over ranks per repetition; every rank also reports its OWN event times)
+    own_us = [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]]
     per_rank = coll.gather_to_root({"rank": info.rank, "device": getattr(backend, "dev_index", None),
                                     "global_env_offset": run.offset,
-                                    "launch_us": statistics.median(kernels) * 1e3 / (args.steps * passes)})
+                                    "launch_us": statistics.median(own_us), "launch_us_min": min(own_us), "launch_us_max": max(own_us),
+                                    "cpu_affinity": getattr(args, "cpu_affinity", None), "numa_node": getattr(args, "numa_node", None)})
     out = None
     if info.is_root:
         wall = statistics.median(walls)
@@ -415,13 +448,18 @@ def run_rank(args, info, backend, make_collective=None):
                 "repetitions": reps,
                 "passes_per_repetition": passes,
                 "calibration_passes": 1 + again,  # untimed passes of K steps between the warm-up and the first repetition
+                "settle_ms": settle_ms,  # untimed stepping right before the first repetition (calibration passes included)
                 "steps_per_repetition": steps_timed,
                 "wall_ms_per_repetition": [w * 1e3 for w in walls],
                 "event_ms_per_repetition": kernels,
+                "event_us_per_step": {"min": min(kernels) * 1e3 / steps_timed, "median": kernel_ms * 1e3 / steps_timed,
+                                      "max": max(kernels) * 1e3 / steps_timed,
+                                      "spread": (max(kernels) - min(kernels)) / kernel_ms},
                 "statistic": "median over repetitions of the max over ranks",
                 "stats_readout_us": stats_readout_us,
                 # CPUs this rank's launching thread and the HIP runtime's helpers were confined to (None = not pinned)
                 "cpu_affinity": getattr(args, "cpu_affinity", None),
+                "numa_node": getattr(args, "numa_node", None),  # the GPU's NUMA node when the block was taken from its local CPUs
             },
             "ranks": per_rank,
             "roofline": {
@@ -443,6 +481,7 @@ def run_rank(args, info, backend, make_collective=None):
         }
         if run.allreduce_note:
             out["config"]["stats_allreduce_note"] = run.allreduce_note
+        out["config"]["comm_watchdog"] = "a native RCCL call timed out and was abandoned" if run.abandoned else "not triggered"
         if getattr(backend, "oversubscribed", False):
             out["oversubscribed"] = "TEST RUN: ranks share GPUs and meet over gloo; value is not a benchmark result"
         roof = out["roofline"]
@@ -508,15 +547,69 @@ def run_rank(args, info, backend, make_collective=None):
             elif note:
                 roof["note"] = note
             out["roofline"] = roof
-        gymrs.sharded.restore_cpus(getattr(args, "cpu_affinity_before", None))  # the CPU baseline may use every core
-        if info.world == 1 and args.cpu_seconds > 0 and hasattr(backend, "cpu_baseline"):
-            out["cpu_baseline"] = backend.cpu_baseline(kind, args.cpu_seconds)
-        elif info.world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
     eng.close()
+    if (info.is_root and info.world == 1 and backend.name == "hip" and not args.rollout and not args.no_configs and args.env == "cartpole"
+            and not args.n_envs and not args.vec and not args.nt and not args.graph):
+        # the other BASELINE.json configs, driver-run: short legs after the headline (its engine is gone: one batch at a time)
+        out["configs"] = {name: measure_config(backend, gymrs, *spec, no_probe=args.no_probe) for name, spec in EXTRA_CONFIGS.items()}
+    if info.is_root:
+        gymrs.sharded.restore_cpus(getattr(args, "cpu_affinity_before", None))  # the CPU baseline may use every core
+        # N > 1: a SHORT sample (the other ranks wait at the barrier below), so that a scaling line still carries the baseline
+        cpu_seconds = args.cpu_seconds if info.world == 1 else min(args.cpu_seconds, 2.0)
+        if cpu_seconds > 0:
+            out["cpu_baseline"] = (backend.cpu_baseline if hasattr(backend, "cpu_baseline") else cpu_baseline)(kind, cpu_seconds)
     coll.barrier()  # every rank leaves the process group together
     coll.close()
+    args.hard_exit = run.abandoned  # a helper thread may still sit inside a native call that never returns
     return out
+
+
+def measure_config(backend, gymrs, env_name, n, nbuf, no_probe=False, repetitions=5):
+    """One short leg for another BASELINE.json config on this GPU: same procedure as the headline (warm-up, settle, R repetitions
+    of >= 5 ms of back-to-back launches between HIP events on the engine's stream, median), reported as a sub-record."""
+    kind, _, bytes_read, bytes_written, workload = ENVS[env_name]
+    bytes_per_step = bytes_read + bytes_written
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if env_name == "pendulum" else 0)
+    eng = backend.make_engine(kind, n, 0, flags, 0)
+    stream = backend.stream_of(eng)
+    act_ptr, act_stride, _ring = backend.make_action_ring(eng, n, nbuf, env_name == "pendulum")
+    eng.reset(seed=0)
+    k = 64
+
+    def timed(n_pass):
+        m0 = backend.mark(stream)
+        for _ in range(n_pass):
+            eng.step_many(act_ptr, act_stride, nbuf, k)
+        m1 = backend.mark(stream)
+        eng.sync()
+        return backend.elapsed_ms(m0, m1)
+
+    timed(2)
+    per_pass = max(timed(4) / 4, 1e-3)                                   # ms per 64 steps
+    timed(max(1, int(SETTLE_SECONDS * 1e3 / per_pass)))                  # settle (untimed)
+    n_pass = max(1, int(math.ceil(MIN_REPETITION_SECONDS * 1e3 / per_pass)))
+    us = sorted(timed(n_pass) * 1e3 / (n_pass * k) for _ in range(repetitions))
+    launch_us = statistics.median(us)
+    stats = eng.stats()
+    eng.close()
+    del _ring
+    achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
+    rec = {"workload": workload if n == ENVS[env_name][1] else f"{env_name} @ {n} envs (every array streams from HBM: 2^24 x 38 B = 640 MB per step)",
+           "lanes": n, "value": n / (launch_us * 1e-6), "unit": "env-steps/s", "launch_us": launch_us, "launch_us_min": us[0], "launch_us_max": us[-1],
+           "repetitions": repetitions, "steps_per_repetition": n_pass * k, "bytes_per_env_step": bytes_per_step,
+           "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBPS, "episodes_finished": float(stats[2])}
+    if n == ENVS[env_name][1]:
+        rec_t, _ = load_pmc("pmc_traffic.json", env_name, kernel_source_sha16())
+        if rec_t:
+            rec["traffic"] = rec_t["bytes_per_launch"]
+            rec["frac_moved"] = rec_t["bytes_per_launch"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
+    if not no_probe:
+        nt = 1 if (n * bytes_per_step <= (48 << 20) or n * bytes_per_step >= (340 << 20)) else 0
+        us_same = backend.copy_probe(n * bytes_read // 16 * 16, n * bytes_written // 16 * 16, max(20, int(2e3 / launch_us)), nt)
+        if us_same:
+            rec["same_footprint_copy_us"] = us_same
+            rec["frac_of_same_footprint_copy"] = us_same / launch_us
+    return rec
 
 
 def main(argv=None) -> int:
@@ -539,12 +632,16 @@ def main(argv=None) -> int:
     os.dup2(2, 1)
     # a few CPUs per rank for the launching thread and the HIP runtime's helpers (sharded.pin_rank_to_cpus says why);
     # the CPU baseline leg gets the full mask back
-    args.cpu_affinity, args.cpu_affinity_before = sharded.pin_rank_to_cpus(info.local_rank, n_local_ranks=info.world)
+    # -- taken from the CPUs local to the rank's GPU (its NUMA node) when the topology can be read
+    args.cpu_affinity, args.cpu_affinity_before, args.numa_node = sharded.pin_rank_near_gpu(info.local_rank, n_local_ranks=info.world)
     backend = HipBackend(args, info)
     out = run_rank(args, info, backend)
     if out is not None:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)
+    if getattr(args, "hard_exit", False):
+        sys.stderr.flush()
+        os._exit(0)
     return 0
 
 

@@ -215,6 +215,16 @@ struct TileRegs {
     static constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS) != 0;
     static constexpr bool TLIM = (FLAGS & GYMRS_TIME_LIMIT) != 0;
     static constexpr bool NT = (FLAGS & kFlagNonTemporal) != 0;
+    // Which accesses carry the hint when the launch asks for it.  The state arrays are the only ones the NEXT step reads
+    // again; actions are read once, rewards / flags / Pendulum's (cos, sin) are written and never read by a step.
+    // GYMRS_EXP_HINTS (developer builds, tools/devbuild.py) overrides the launch flag per class of access:
+    // bit 0 state loads, bit 1 state stores, bit 2 action loads, bit 3 reward / done / truncated / obs stores.
+#ifdef GYMRS_EXP_HINTS
+    static constexpr bool NT_SL = (GYMRS_EXP_HINTS & 1) != 0, NT_SS = (GYMRS_EXP_HINTS & 2) != 0, NT_A = (GYMRS_EXP_HINTS & 4) != 0,
+                          NT_O = (GYMRS_EXP_HINTS & 8) != 0;
+#else
+    static constexpr bool NT_SL = NT, NT_SS = NT, NT_A = NT, NT_O = NT;
+#endif
     // Episode bookkeeping of the per-step kernel goes through the reset log (StepArgs::reset_log) when nothing in the
     // step needs ep_start itself: statistics on, no time limit, constant reward (return = +-length).
     static constexpr bool LOGGED = STATS && !TLIM && Env::kConstReward && Env::kUseResetLog;
@@ -233,9 +243,9 @@ __device__ __forceinline__ void load_tile(const StepArgs& a, uint64_t base, Tile
     using R = TileRegs<Env, VEC, FLAGS>;
     using Action = typename Env::Action;
 #pragma unroll
-    for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, 0.0f);
-    if (!ROLL) d.act = load_vec<Action, kVec, R::NT>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
-    if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, uint8_t(0));
+    for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, kVec, R::NT_SL>(a.s[j], base, a.n, FULL, 0.0f);
+    if (!ROLL) d.act = load_vec<Action, kVec, R::NT_A>(static_cast<const Action*>(a.action), base, a.n, FULL, Action(0));
+    if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, kVec, R::NT_SL>(a.beyond, base, a.n, FULL, uint8_t(0));
     if (ROLL ? (R::STATS || R::TLIM) : (R::TLIM && !Env::kNeverTerminates))
         d.ep_start = load_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, 0u);
 }
@@ -508,13 +518,13 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
     using R = TileRegs<Env, VEC, FLAGS>;
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
 #pragma unroll
-    for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::NT>(a.s[j], base, a.n, FULL, d.st[j]);
-    if (!skip_reward) store_vec<float, kVec, R::NT>(a.reward, base, a.n, FULL, out.reward);
+    for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::NT_SS>(a.s[j], base, a.n, FULL, d.st[j]);
+    if (!skip_reward) store_vec<float, kVec, R::NT_O>(a.reward, base, a.n, FULL, out.reward);
     // An env that never terminates never changes `done` (reset() zeroed it), and its `truncated` flag is the same
     // for every lane: neither is rewritten while it already holds the right value (2 of Pendulum's 34 real bytes).
-    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::NT>(a.done, base, a.n, FULL, out.done);
-    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::NT>(a.truncated, base, a.n, FULL, out.trunc);
-    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT>(a.beyond, base, a.n, FULL, d.beyond);
+    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::NT_O>(a.done, base, a.n, FULL, out.done);
+    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::NT_O>(a.truncated, base, a.n, FULL, out.trunc);
+    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT_SS>(a.beyond, base, a.n, FULL, d.beyond);
     if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, d.ep_start);
     if (Env::kHasObsExtra) {
         Vec<float, kVec> oc, os;
@@ -528,8 +538,8 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
 #pragma unroll
             for (int k = 0; k < kVec; ++k) sincosf_(d.st[0].v[k], &os.v[k], &oc.v[k]);
         }
-        store_vec<float, kVec, R::NT>(a.obs_cos, base, a.n, FULL, oc);
-        store_vec<float, kVec, R::NT>(a.obs_sin, base, a.n, FULL, os);
+        store_vec<float, kVec, R::NT_O>(a.obs_cos, base, a.n, FULL, oc);
+        store_vec<float, kVec, R::NT_O>(a.obs_sin, base, a.n, FULL, os);
     }
     GYMRS_STAMP(5); // stores issued
 #ifdef GYMRS_TRACE_TIMES

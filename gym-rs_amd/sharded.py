@@ -108,6 +108,96 @@ def pin_rank_to_cpus(local_rank: int, width: int = 4, env=None, n_local_ranks: i
     return mine, previous
 
 
+def _parse_cpulist(text: str):
+    cpus = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_map(sysfs: str = "/sys", env=None):
+    """[(numa_node, [cpus local to it])] for the GPUs a HIP process would enumerate, in HIP's order, WITHOUT starting the HIP
+    runtime (its helper threads inherit the affinity mask set before it starts): the KFD topology nodes with a GPU, in node
+    order (the order ROCr and HIP enumerate them in), mapped to their PCI function's numa_node / local_cpulist, then filtered
+    by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES when those are plain index lists.  None when the topology cannot be read
+    (no KFD, a container without /sys/class/kfd): the caller falls back to index-based blocks."""
+    env = os.environ if env is None else env
+    base = os.path.join(sysfs, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted((int(d) for d in os.listdir(base) if d.isdigit()))
+    except OSError:
+        return None
+    gpus = []
+    for nd in nodes:
+        props = {}
+        try:
+            with open(os.path.join(base, str(nd), "properties")) as f:
+                for line in f:
+                    k, _, v = line.strip().partition(" ")
+                    props[k] = v
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) == 0:  # a CPU node
+            continue
+        try:
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (KeyError, ValueError):
+            return None
+        bdf = f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}"
+        dev = os.path.join(sysfs, "bus", "pci", "devices", bdf)
+        try:
+            with open(os.path.join(dev, "numa_node")) as f:
+                node = int(f.read().strip())
+            with open(os.path.join(dev, "local_cpulist")) as f:
+                cpus = _parse_cpulist(f.read())
+        except (OSError, ValueError):
+            return None
+        gpus.append((node, cpus))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):  # applied in this order by the runtimes
+        val = env.get(var)
+        if val:
+            try:
+                gpus = [gpus[int(i)] for i in val.split(",") if i.strip() != ""]
+            except (ValueError, IndexError):
+                return None  # UUIDs or out-of-range entries: do not guess
+    return gpus or None
+
+
+def pin_rank_near_gpu(local_rank: int, width: int = 4, env=None, n_local_ranks: int = 1, sysfs: str = "/sys"):
+    """pin_rank_to_cpus, but the block is taken from the CPUs LOCAL to the rank's GPU (its PCI function's NUMA node): with 8
+    launch threads on a 2-socket host a thread on the far socket pays a cross-socket hop for every doorbell and every
+    mapped-memory word.  Ranks whose GPUs share a node take consecutive blocks of that node's CPUs.  Returns
+    (cpus, previous, numa_node); falls back to pin_rank_to_cpus (numa_node None) when the topology is not readable or the
+    node's CPUs are not in this process's mask."""
+    env = os.environ if env is None else env
+    gpus = None if env.get("GYMRS_NO_NUMA_PIN") == "1" else gpu_numa_map(sysfs, env)
+    try:
+        previous = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None, None, None
+    if env.get("GYMRS_NO_CPU_PIN") == "1":
+        return None, previous, None
+    if gpus and 0 <= local_rank < len(gpus):
+        node, local = gpus[local_rank]
+        usable = [c for c in local if c in set(previous)]
+        sharing = [r for r in range(min(n_local_ranks, len(gpus))) if gpus[r][0] == node]  # local ranks whose GPU sits on this node
+        if usable and local_rank in sharing:
+            w = max(1, min(width, len(usable) // max(1, len(sharing))))
+            start = sharing.index(local_rank) * w
+            mine = usable[start:start + w]
+            if len(mine) == w:
+                try:
+                    os.sched_setaffinity(0, mine)
+                    return mine, previous, node
+                except OSError:
+                    pass
+    mine, previous = pin_rank_to_cpus(local_rank, width=width, env=env, n_local_ranks=n_local_ranks)
+    return mine, previous, None
+
+
 def restore_cpus(previous) -> None:
     if previous:
         try:
@@ -130,7 +220,10 @@ class Collective:
             import torch.distributed as dist
 
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            kwargs = {}
+            import datetime
+
+            # a rendezvous or collective whose peers never arrive ends the job with an error instead of hanging it
+            kwargs = {"timeout": datetime.timedelta(seconds=int(os.environ.get("GYMRS_DIST_TIMEOUT", "300")))}
             if backend == "nccl" and device is not None:
                 kwargs["device_id"] = device
             dist.init_process_group(backend, **kwargs)
@@ -181,6 +274,30 @@ class Collective:
             self.active = False
 
 
+def call_with_timeout(fn, seconds: float):
+    """Run fn() in a daemon thread; (True, result) when it returned in time, (False, exception or None) otherwise.  A native
+    call that never returns (a rank stuck inside ncclCommInitRank or a collective whose peers never arrive) cannot be
+    cancelled -- the thread is left behind and the caller goes on without whatever it was setting up."""
+    import threading
+
+    box = {}
+
+    def work():
+        try:
+            box["result"] = fn()
+        except BaseException as exc:  # noqa: BLE001 -- reported to the caller
+            box["error"] = exc
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return False, None
+    if "error" in box:
+        return False, box["error"]
+    return True, box.get("result")
+
+
 class ShardedRun:
     """One rank's shard of a lane-sharded batch plus the job-level bookkeeping.
 
@@ -197,38 +314,78 @@ class ShardedRun:
         self.engine = make_engine(self.offset, self.lanes_per_rank)
         self.allreduce_path = "none (one rank)"
         self.allreduce_note = None
+        self.abandoned = False  # a native RCCL call timed out and may still be stuck in a helper thread
+        self._leaked = []
 
-    def setup_stats_allreduce(self, prefer_native: bool = True) -> str:
+    def setup_stats_allreduce(self, prefer_native: bool = True, make_probe_engine: Optional[Callable] = None,
+                              timeout: Optional[float] = None) -> str:
         """Choose how the 4 statistics doubles are summed over ranks.  Preferred: the C ABI's own RCCL communicator
         (rank 0's ncclUniqueId travels through the torch.distributed store).  If the library's RCCL path cannot be
-        set up, torch.distributed's all-reduce (the same RCCL underneath) is used and the reason is kept."""
+        set up, torch.distributed's all-reduce (the same RCCL underneath) is used and the reason is kept.
+
+        First contact is guarded (a rank stuck inside ncclCommInitRank used to hang the job): every native
+        step runs under a watchdog of `timeout` seconds (GYMRS_COMM_TIMEOUT, default 90), and before the run's own engine
+        joins a communicator a throw-away PROBE engine (make_probe_engine: a few lanes, its own stream) does comm_init + one
+        all-reduce -- a collective that never completes blocks the stream it was enqueued on for good, which must not be the
+        stream the benchmark runs on.  Any rank failing or timing out anywhere -> ALL ranks use torch.distributed (agreed
+        through torch.distributed itself), `allreduce_note` says why, and `abandoned` tells the caller that a native call may
+        still be stuck in a helper thread (leave with os._exit once the result is out)."""
         if not self.coll.active:
             return self.allreduce_path
         self.allreduce_path = f"torch.distributed({self.coll.backend})"
-        if prefer_native and hasattr(self.engine, "comm_init"):
-            # 1. every rank checks that it can reach the library's RCCL entry points at all (a rank that cannot must not
-            #    leave the others waiting inside ncclCommInitRank); rank 0's id is the one that is used
+        if not (prefer_native and hasattr(self.engine, "comm_init")):
+            return self.allreduce_path
+        if timeout is None:
+            timeout = float(os.environ.get("GYMRS_COMM_TIMEOUT", "90"))
+        world = float(self.info.world)
+
+        def all_ok(ok: bool) -> bool:
+            return self.coll.sum([1.0 if ok else 0.0])[0] == world
+
+        def join(engine, what: str):
+            """comm_unique_id on rank 0 -> broadcast -> comm_init on every rank (watched).  Returns (ok on ALL ranks, local error)."""
             uid, err = None, None
-            try:
-                uid = self.engine.comm_unique_id()
+            try:  # every rank checks that it can reach the library's RCCL entry points at all; rank 0's id is the one used
+                uid = engine.comm_unique_id()
             except Exception as exc:  # librccl missing on this rank
-                err = repr(exc)
-            if self.coll.sum([0.0 if err else 1.0])[0] != float(self.info.world):
-                self.allreduce_note = f"native RCCL path unavailable on at least one rank: {err}"
-                return self.allreduce_path
-            # 2. rank 0's 128 bytes travel through the torch.distributed store; every rank joins
+                err = f"{what}: comm_unique_id: {exc!r}"
+            if not all_ok(err is None):
+                return False, err or f"{what}: RCCL entry points unavailable on another rank"
             uid = self.coll.broadcast_from_root(uid)
-            ok = 0.0
-            try:
-                self.engine.comm_init(self.info.world, self.info.rank, uid)
-                ok = 1.0
-            except Exception as exc:
-                err = repr(exc)
-            # 3. all ranks or none: a communicator only part of the ranks hold must never see a collective
-            if self.coll.sum([ok])[0] == float(self.info.world):
-                self.allreduce_path = "gymrs_allreduce_stats (RCCL via the C ABI)"
-            else:
-                self.allreduce_note = f"native RCCL path unavailable: {err}"
+            done, res = call_with_timeout(lambda: engine.comm_init(self.info.world, self.info.rank, uid), timeout)
+            if not done:
+                err = f"{what}: comm_init " + (f"failed: {res!r}" if res is not None else f"did not return within {timeout:.0f} s")
+                self.abandoned = self.abandoned or res is None
+            # all ranks or none: a communicator only part of the ranks hold must never see a collective
+            if not all_ok(done):
+                return False, err or f"{what}: comm_init failed or timed out on another rank"
+            return True, None
+
+        def trial(engine, what: str):
+            done, res = call_with_timeout(engine.allreduce_stats, timeout)
+            err = None
+            if not done:
+                err = f"{what}: all-reduce " + (f"failed: {res!r}" if res is not None else f"did not complete within {timeout:.0f} s")
+                self.abandoned = self.abandoned or res is None
+            if not all_ok(done):
+                return False, err or f"{what}: all-reduce failed or timed out on another rank"
+            return True, None
+
+        if make_probe_engine is not None:
+            probe = make_probe_engine(self.offset)
+            ok, err = join(probe, "probe engine")
+            if ok:
+                ok, err = trial(probe, "probe engine")
+            if not ok:
+                self.allreduce_note = f"native RCCL path unavailable ({err}); statistics summed by torch.distributed on ALL ranks"
+                self._leaked.append(probe)  # never closed: its stream may hold a collective that cannot finish
+                return self.allreduce_path
+            probe.close()
+        ok, err = join(self.engine, "engine")
+        if ok:
+            self.allreduce_path = "gymrs_allreduce_stats (RCCL via the C ABI)"
+        else:
+            self.allreduce_note = f"native RCCL path unavailable ({err}); statistics summed by torch.distributed on ALL ranks"
         return self.allreduce_path
 
     @property
@@ -238,7 +395,15 @@ class ShardedRun:
     def allreduce_stats(self) -> np.ndarray:
         """{sum_return, sum_length, n_episodes, n_steps} of the WHOLE batch, identical on every rank."""
         if self.native:
-            return np.asarray(self.engine.allreduce_stats(), dtype=np.float64)
+            # watched: a native collective that never completes ends this rank loudly (the launcher then ends the others)
+            timeout = float(os.environ.get("GYMRS_COMM_TIMEOUT", "90"))
+            done, res = call_with_timeout(self.engine.allreduce_stats, timeout)
+            if not done:
+                sys.stderr.write(f"gymrs sharded: rank {self.info.rank}: gymrs_allreduce_stats "
+                                 + (f"failed: {res!r}" if res is not None else f"did not complete within {timeout:.0f} s") + "\n")
+                sys.stderr.flush()
+                os._exit(3)
+            return np.asarray(res, dtype=np.float64)
         return self.coll.sum(self.engine.stats())
 
     def check_total_steps(self, total_stats: np.ndarray, steps_per_lane: int) -> None:

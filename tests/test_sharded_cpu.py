@@ -1,4 +1,4 @@
-"""The N>1 path on CPU (world_size 2, gloo): bench.py's own per-rank function -- sharding by global env offset,
+"""The N>1 path on CPU (world_size 2 and 8, gloo): bench.py's own per-rank function -- sharding by global env offset,
 repetitions, max-over-ranks, the statistics all-reduce after the clock, the line rank 0 prints -- with the f32 twin
 standing in for the GPU shard (it supplies ONLY the per-shard stepping and statistics).  Plus the launcher pieces
 (`python bench.py --gpus N` becoming N ranks) that do not need a device."""
@@ -104,50 +104,118 @@ class TwinBackend:
 '''
 
 WORKER = TWIN_BACKEND + r'''
-import importlib, json, os, sys
+import importlib, json, os, sys, time
 sys.path.insert(0, sys.argv[1])
 import bench
 gymrs = importlib.import_module("gym-rs_amd")
-args = bench.parse_args(["--gpus", "2", "--steps", "7", "--warmup", "5", "--n-envs", "3001", "--action-buffers", "4",
+world, comm_mode = int(sys.argv[3]), sys.argv[4]
+args = bench.parse_args(["--gpus", str(world), "--steps", "7", "--warmup", "5", "--n-envs", "3001", "--action-buffers", "4",
                          "--cpu-seconds", "0", "--repetitions", "3", "--no-probe"])
 bench.MIN_REPETITION_SECONDS = 0.0  # one pass of K steps per repetition keeps the twin run short
+bench.SETTLE_SECONDS = 0.0
 info = gymrs.sharded.rank_info()
-assert info.world == 2 and info.launched
+assert info.world == world and info.launched
 backend = TwinBackend(gymrs)
+
+if comm_mode != "none":
+    # A stand-in for the C ABI's RCCL entry points (gymrs_comm_unique_id / _comm_init / _allreduce_stats): "ok" works (the sum
+    # itself travels over gloo), the other modes misbehave on ONE rank the way a broken first contact would.
+    import numpy as np
+
+    class CommShard(TwinShard):
+        is_probe = False
+
+        def comm_unique_id(self):
+            return b"u" * 128
+
+        def comm_init(self, n_ranks, rank, uid):
+            assert uid == b"u" * 128 and n_ranks == world
+            if comm_mode == "init_hangs" and rank == 1 and self.is_probe:
+                time.sleep(3600)
+            if comm_mode == "init_fails" and rank == world - 1 and self.is_probe:
+                raise RuntimeError("ncclCommInitRank: unhandled system error (test)")
+            self.joined = True
+
+        seq = 0
+
+        def allreduce_stats(self):
+            # the stand-in's own "wire" (files in the test's directory), independent of the torch.distributed group the way
+            # the library's RCCL communicator is: a rank that never shows up leaves its peers waiting HERE, not in gloo
+            assert self.joined
+            if comm_mode == "trial_hangs" and info.rank == 0 and self.is_probe:
+                time.sleep(3600)
+            CommShard.seq += 1
+            tag = ("p" if self.is_probe else "e") + str(CommShard.seq)
+            mine = os.path.join(sys.argv[2], f"ar_{tag}_{info.rank}.npy")
+            np.save(mine + ".tmp.npy", np.asarray(self.stats(), np.float64))
+            os.replace(mine + ".tmp.npy", mine)
+            total = np.zeros(4)
+            for r in range(world):
+                path = os.path.join(sys.argv[2], f"ar_{tag}_{r}.npy")
+                while not os.path.exists(path):
+                    time.sleep(0.01)
+                total += np.load(path)
+            return total
+
+    def make_engine(kind, n, offset, flags, vec):
+        e = CommShard(backend.twin, gymrs, kind, n, offset, flags)
+        backend.engines.append(e)
+        return e
+
+    def probe_engine(kind, offset, flags):
+        e = CommShard(backend.twin, gymrs, kind, 16, offset, flags)
+        e.is_probe = True
+        e.reset(0)
+        return e
+
+    backend.make_engine = make_engine
+    backend.probe_engine = probe_engine
+
 out = bench.run_rank(args, info, backend)
 shard = backend.engines[0]
 state = shard.get_state()
+import numpy as np
 np.save(os.path.join(sys.argv[2], f"state{info.rank}.npy"), state)
 if info.is_root:
-    print("RESULT " + json.dumps(out))
+    print("RESULT " + json.dumps(out), flush=True)
 else:
     assert out is None
+if getattr(args, "hard_exit", False):  # a helper thread still sits in the stand-in's sleep
+    sys.stdout.flush()
+    os._exit(0)
 '''
 
 
-def test_bench_rank_logic_two_ranks_gloo(tmp_path, twin):
+def run_workers(tmp_path, world, comm_mode="none", timeout=900, extra_env=None):
     gymrs = importlib.import_module("gym-rs_amd")
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    cmd = gymrs.sharded.spawn_command(str(script), [str(ROOT), str(tmp_path)], 2)
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    cmd = gymrs.sharded.spawn_command(str(script), [str(ROOT), str(tmp_path), str(world), comm_mode], world)
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("RESULT ")]
     assert len(line) == 1, res.stdout[-2000:]
-    out = json.loads(line[0][len("RESULT "):])
-    n, steps, warmup, reps = 3001, 7, 5, 3
+    return json.loads(line[0][len("RESULT "):])
+
+
+def check_against_one_unsharded_twin(tmp_path, twin, out, world, n=3001, steps=7, warmup=5, reps=3):
+    gymrs = importlib.import_module("gym-rs_amd")
     passes = out["timing"]["passes_per_repetition"]
-    assert out["n_gpus"] == 2 and out["config"]["total_lanes"] == 2 * n and out["config"]["lanes_per_gpu"] == n
+    assert out["n_gpus"] == world and out["config"]["total_lanes"] == world * n and out["config"]["lanes_per_gpu"] == n
     assert out["timing"]["repetitions"] == reps and len(out["timing"]["wall_ms_per_repetition"]) == reps
-    assert [r["global_env_offset"] for r in out["ranks"]] == [0, n]
-    assert out["config"]["stats_allreduce"] == "torch.distributed(gloo)"  # the twin has no RCCL communicator
-    assert out["value"] == pytest.approx(2 * n * steps * passes / (out["ms_per_step"] * 1e-3 * steps * passes), rel=1e-9)
-    # the same batch, UNSHARDED, same schedule: warm-up, one calibration pass, stats_clear, then the timed steps
+    assert [r["rank"] for r in out["ranks"]] == list(range(world))
+    assert [r["global_env_offset"] for r in out["ranks"]] == [k * n for k in range(world)]
+    for r in out["ranks"]:  # every rank's own launch time, with its spread over the repetitions
+        assert 0 < r["launch_us_min"] <= r["launch_us"] <= r["launch_us_max"]
+    ev = out["timing"]["event_us_per_step"]
+    assert ev["min"] <= ev["median"] <= ev["max"]
+    assert out["value"] == pytest.approx(world * n * steps * passes / (out["ms_per_step"] * 1e-3 * steps * passes), rel=1e-9)
+    # the same batch, UNSHARDED, same schedule: warm-up, the calibration passes, stats_clear, then the timed steps
     from oracle.bindings import TwinEngine
 
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
-    full = TwinEngine(twin, 0, 2 * n, gymrs.engine.default_params(0), flags=flags, gid0=0)
+    full = TwinEngine(twin, 0, world * n, gymrs.engine.default_params(0), flags=flags, gid0=0)
     ring = [full.fill_actions(1, b) for b in range(4)]
     full.reset(0)
 
@@ -164,10 +232,40 @@ def test_bench_rank_logic_two_ranks_gloo(tmp_path, twin):
     want = full.stats()
     got = out["episodes"]
     assert (got["sum_return"], got["sum_length"], got["n_episodes"]) == (want[0], want[1], want[2])
-    assert want[3] == 2 * n * steps * passes * reps
+    assert want[3] == world * n * steps * passes * reps
     # shard invariance of the state itself: rank r's lanes are lanes [r*n, (r+1)*n) of the unsharded batch, bit for bit
-    cat = np.concatenate([np.load(tmp_path / f"state{r}.npy") for r in range(2)], axis=1)
+    cat = np.concatenate([np.load(tmp_path / f"state{r}.npy") for r in range(world)], axis=1)
     assert np.array_equal(cat.view(np.uint32), full.get_state().view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rank_logic_gloo(tmp_path, twin, world):
+    '''bench.run_rank itself with world_size 2 and 8 (BASELINE configs[4]'s shape: 8 shards, global env ids rank * n + i).'''
+    out = run_workers(tmp_path, world)
+    assert out["config"]["stats_allreduce"] == "torch.distributed(gloo)"  # the twin has no RCCL communicator
+    assert "cpu_baseline" not in out  # --cpu-seconds 0
+    check_against_one_unsharded_twin(tmp_path, twin, out, world)
+
+
+@pytest.mark.parametrize("comm_mode", ["ok", "init_hangs", "init_fails", "trial_hangs"])
+def test_first_contact_with_the_native_collective_is_watched(tmp_path, twin, comm_mode):
+    '''a rank stuck inside ncclCommInitRank (or a first all-reduce whose peers never arrive) used to hang the
+    job.  The native path is first tried on a throw-away probe engine under a watchdog; whatever goes wrong on ANY rank, ALL
+    ranks fall back to torch.distributed, the line says why, and the statistics are still those of the unsharded batch.'''
+    out = run_workers(tmp_path, 2, comm_mode, extra_env={"GYMRS_COMM_TIMEOUT": "3"})
+    cfg = out["config"]
+    if comm_mode == "ok":
+        assert cfg["stats_allreduce"].startswith("gymrs_allreduce_stats") and "stats_allreduce_note" not in cfg
+        assert cfg["comm_watchdog"] == "not triggered"
+    else:
+        assert cfg["stats_allreduce"] == "torch.distributed(gloo)"
+        note = cfg["stats_allreduce_note"]
+        assert "torch.distributed on ALL ranks" in note and "probe engine" in note
+        if comm_mode == "trial_hangs":  # rank 0 (the one that prints) is the rank that gave up waiting
+            assert "did not complete within 3 s" in note and cfg["comm_watchdog"].startswith("a native RCCL call timed out")
+        if comm_mode == "init_fails":
+            assert "failed" in note or "another rank" in note
+    check_against_one_unsharded_twin(tmp_path, twin, out, 2)
 
 
 def test_launcher_pieces():
@@ -234,3 +332,64 @@ print(json.dumps(out))
     if blocks >= 2:
         assert out["ranks"][0]["mine"] != out["ranks"][1]["mine"]
     assert out["off"] == [None, True]
+
+
+def test_rank_pinning_near_the_gpu_from_a_fake_topology(tmp_path):
+    """sharded.pin_rank_near_gpu (VERDICT r2 "next" #1d): the block of CPUs comes from the GPU's own NUMA node -- KFD topology node
+    -> PCI function -> local_cpulist -- ranks sharing a node take consecutive blocks, ROCR/HIP_VISIBLE_DEVICES re-index the GPUs,
+    and anything unreadable falls back to the index-based blocks.  A fake /sys stands in for an 8-GPU, 2-socket host whose CPU
+    numbers are this process's own allowed CPUs (so that sched_setaffinity accepts them)."""
+    code = r'''
+import importlib, json, os, sys
+sys.path.insert(0, sys.argv[1])
+sh = importlib.import_module("gym-rs_amd").sharded
+root = sys.argv[2]
+allowed = sorted(os.sched_getaffinity(0))
+half = len(allowed) // 2
+sockets = [allowed[:half], allowed[half:]]
+def cpulist(c): return ",".join(str(x) for x in c)
+nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+for i in range(2):  # two CPU nodes first, as KFD lists them
+    os.makedirs(os.path.join(nodes, str(i)))
+    open(os.path.join(nodes, str(i), "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+for g in range(8):
+    bus = 0x10 + 0x10 * g
+    os.makedirs(os.path.join(nodes, str(2 + g)))
+    open(os.path.join(nodes, str(2 + g), "properties"), "w").write(f"cpu_cores_count 0\nsimd_count 1024\nlocation_id {bus << 8}\ndomain 0\n")
+    dev = os.path.join(root, "bus", "pci", "devices", f"0000:{bus:02x}:00.0")
+    os.makedirs(dev)
+    open(os.path.join(dev, "numa_node"), "w").write(f"{g // 4}\n")
+    open(os.path.join(dev, "local_cpulist"), "w").write(cpulist(sockets[g // 4]) + "\n")
+out = {"allowed": allowed, "map": sh.gpu_numa_map(root, env={}), "ranks": []}
+for rank in range(8):
+    mine, before, node = sh.pin_rank_near_gpu(rank, n_local_ranks=8, sysfs=root, env={})
+    out["ranks"].append({"mine": mine, "node": node, "now": sorted(os.sched_getaffinity(0))})
+    sh.restore_cpus(before)
+out["visible"] = sh.gpu_numa_map(root, env={"HIP_VISIBLE_DEVICES": "5,1"})
+out["uuid"] = sh.gpu_numa_map(root, env={"ROCR_VISIBLE_DEVICES": "GPU-abcdef"})
+out["missing"] = sh.gpu_numa_map(os.path.join(root, "nope"), env={})
+mine, before, node = sh.pin_rank_near_gpu(3, n_local_ranks=8, sysfs=os.path.join(root, "nope"), env={})
+out["fallback"] = {"mine": mine, "node": node}
+sh.restore_cpus(before)
+mine, before, node = sh.pin_rank_near_gpu(3, n_local_ranks=8, sysfs=root, env={"GYMRS_NO_CPU_PIN": "1"})
+out["off"] = [mine, node, sorted(os.sched_getaffinity(0)) == allowed]
+print(json.dumps(out))
+'''
+    res = subprocess.run([sys.executable, "-c", code, str(ROOT), str(tmp_path / "sys")], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    allowed = out["allowed"]
+    if len(allowed) < 8:
+        pytest.skip("fewer than 8 CPUs allowed: nothing to partition")
+    half = len(allowed) // 2
+    sockets = [allowed[:half], allowed[half:]]
+    assert [m[0] for m in out["map"]] == [0, 0, 0, 0, 1, 1, 1, 1] and out["map"][5][1] == sockets[1]
+    width = max(1, min(4, half // 4))
+    for rank, r in enumerate(out["ranks"]):
+        node, k = rank // 4, rank % 4
+        assert r["node"] == node and r["mine"] == sockets[node][k * width:(k + 1) * width] == r["now"], (rank, r)
+    assert len({tuple(r["mine"]) for r in out["ranks"]}) == 8  # no two ranks share a block
+    assert [m[0] for m in out["visible"]] == [1, 0]  # HIP_VISIBLE_DEVICES=5,1 -> GPU 5 (node 1), GPU 1 (node 0)
+    assert out["uuid"] is None and out["missing"] is None
+    assert out["fallback"]["node"] is None and out["fallback"]["mine"] is not None  # index-based block, as before
+    assert out["off"] == [None, None, True]

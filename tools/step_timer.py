@@ -51,11 +51,12 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--engine-first", type=int, default=0, help="create the engines before the action ring is allocated")
     ap.add_argument("--ring-2d", type=int, default=0)
+    ap.add_argument("--nbuf", type=int, default=32, help="action buffers in the ring (32 = bench.py's default)")
     args = ap.parse_args()
     libs = [Lib(p) for p in (args.lib or [ROOT / "gym-rs_amd" / "libgymrs_amd.so"])]
     flags = args.flags if args.flags >= 0 else (7 if args.env == 2 else 3)
     torch.cuda.init()
-    nbuf = 32
+    nbuf = args.nbuf
     esz = 4 if args.env == 2 else 1
     ring = None
     if not args.engine_first:
