@@ -22,7 +22,10 @@ CSRC = PKG / "csrc"
 ORACLE = ROOT / "oracle"
 
 HIP_SOURCES = [CSRC / "gymrs_step_cartpole.hip", CSRC / "gymrs_step_mountain_car.hip", CSRC / "gymrs_step_pendulum.hip",
-               CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip"]
+               CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip", CSRC / "gymrs_aql.hip"]
+# The per-step kernels once more as a stand-alone gfx950 code object (device-only compile), embedded into the library by
+# gymrs_aql.hip (.incbin) and loaded through HSA by the engine's own AQL dispatcher.
+AQL_KERNELS = CSRC / "gymrs_step_aql.hip"
 # every header of the kernel library: the same glob bench.kernel_source_sha16() hashes (a hand-kept
 # list had missed gymrs_json.h and gymrs_pcg64.h, so editing them did not rebuild the library)
 HIP_HEADERS = sorted(CSRC.glob("gymrs_*.h")) + [ROOT / "include" / "gymrs_amd.h"]
@@ -72,18 +75,28 @@ def build_hip(force: bool = False, extra_flags=(), out: Path | None = None) -> P
     lib = Path(out) if out else LIB
     objdir = lib.parent / "_obj" / lib.stem
     hdr_deps = HIP_HEADERS + [Path(__file__)]
-    if not force and not extra_flags and _newer(lib, HIP_SOURCES + hdr_deps):
+    if not force and not extra_flags and _newer(lib, HIP_SOURCES + [AQL_KERNELS] + hdr_deps):
         return lib
     objdir.mkdir(parents=True, exist_ok=True)
     hipcc = _hipcc()
-    jobs = []
+    hsaco = objdir / "gymrs_aql_kernels.hsaco"
+    jobs, after = [], []
+    hsaco_stale = force or bool(extra_flags) or not _newer(hsaco, [AQL_KERNELS] + hdr_deps)
+    if hsaco_stale:
+        jobs.append([hipcc, "--cuda-device-only", "--no-gpu-bundle-output", *[f for f in HIPCC_FLAGS if f != "-fPIC"], *extra_flags,
+                     f"-I{ROOT / 'include'}", f"-I{CSRC}", AQL_KERNELS, "-o", hsaco])
     for src in HIP_SOURCES:
         obj = objdir / (src.stem + ".o")
-        if force or extra_flags or not _newer(obj, [src] + hdr_deps):
-            jobs.append([hipcc, *HIPCC_FLAGS, *extra_flags, f"-I{ROOT / 'include'}", f"-I{CSRC}", "-c", src, "-o", obj])
+        embeds = src.stem == "gymrs_aql"  # .incbin of the code object: compiled after it
+        if force or extra_flags or not _newer(obj, [src] + hdr_deps) or (embeds and hsaco_stale):
+            cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, f"-I{ROOT / 'include'}", f"-I{CSRC}", f'-DGYMRS_AQL_HSACO="{hsaco}"', "-c", src, "-o", obj]
+            (after if embeds else jobs).append(cmd)
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
         list(pool.map(_run, jobs))
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(objdir / (s.stem + ".o") for s in HIP_SOURCES), "-o", lib, "-ldl"])
+    for cmd in after:
+        _run(cmd)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(objdir / (s.stem + ".o") for s in HIP_SOURCES), "-o", lib, "-ldl",
+          "-L/opt/rocm/lib", "-lhsa-runtime64"])
     return lib
 
 

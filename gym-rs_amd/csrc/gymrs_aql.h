@@ -1,0 +1,58 @@
+// gymrs_aql.h -- the engine's own AQL dispatcher: chains of per-step launches written straight into an HSA queue.
+//
+// Why (measured on MI355X, tools/aql/aql_probe.cpp, profiles/r03_aql_probe.log): the HIP runtime gives EVERY launch an
+// agent-scope acquire and an agent-scope RELEASE fence (AQL header 0xb02).  The release is an L2 write-back at the end of
+// the kernel, and for a kernel of the step's shape (17 B read + 21 B written per lane, 2^20 lanes) it costs 1.6-1.9 us per
+// launch: 7.0 us per launch with both fences, 5.1 with the acquire alone -- the acquire (L1 / scalar-cache invalidate) is
+// free.  A chain of gymrs_step_many launches does not need the write-back between its links: tile i is stepped by workgroup
+// i in every launch, workgroups are dealt round-robin to the XCDs, so the lines launch t leaves dirty in an XCD's L2 are
+// read by launch t + 1 on that very XCD.  Only whoever reads the arrays AFTER the chain (another kernel, a copy, the host)
+// needs them written back, so the chain's last packet carries a system-scope release.  HIP has no way to say that; AQL has:
+// the fence scopes are two fields of the packet header.  As a by-product a launch costs the host ~0.3 us instead of 2.5-3.5.
+//
+// The dispatcher is an ALTERNATIVE SUBMISSION PATH for the same kernels (the same templates compiled once more into a
+// stand-alone code object, gymrs_step_aql.hip), not another implementation: everything it cannot do -- or any device on which
+// its self-check fails -- goes through HIP launches as before.  GYMRS_AQL=0 in the environment switches it off.
+//
+// Ordering against the engine's HIP stream (gymrs_step_many is asynchronous ON THAT STREAM):
+//   begin: hipStreamWriteValue32(stream, in_flag, seq) behind whatever is enqueued there; the chain's first packet is a
+//          one-wave kernel that waits for in_flag >= seq (bounded: ~2 s, then it reports and lets the chain run);
+//   end:   the chain's last packet (system-scope release) stores seq into out_flag (signal memory); the stream gets a
+//          hipStreamWaitValue32(out_flag >= seq), so everything enqueued on it later -- and gymrs_sync -- comes after the chain.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+namespace gymrs {
+
+struct AqlKernel {
+    uint64_t object = 0; // kernel descriptor address
+    uint32_t kernarg_bytes = 0, group_bytes = 0, private_bytes = 0;
+};
+
+class AqlChain;
+
+// One chain object per engine (its own HSA queue).  nullptr + *why when the path is not available: no large-BAR access to
+// device memory, no stream memory operations, a failed self-check, GYMRS_AQL=0, ...
+AqlChain* aql_create(int hip_device, std::string* why);
+void aql_destroy(AqlChain* c);
+bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out);
+
+// Largest kernel-argument block one dispatch may carry.
+constexpr size_t kAqlKernargSlot = 512;
+
+// begin -> dispatch ... dispatch -> end.  `stream` is the engine's HIP stream.  On failure *err says why and the chain object
+// stays usable only for aql_destroy (the engine then falls back to HIP launches for good).
+bool aql_begin(AqlChain* c, hipStream_t stream, std::string* err);
+// grid_workitems = workgroups * workgroup_size.  Kernel arguments are copied.
+bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes,
+                  std::string* err);
+bool aql_end(AqlChain* c, hipStream_t stream, std::string* err);
+// != 0 once a chain's first packet gave up waiting for the stream (checked by gymrs_sync); cleared by the call
+uint32_t aql_take_error(AqlChain* c);
+void aql_host_wait(AqlChain* c); // (experiment knob GYMRS_AQL_LAZY_WAIT)
+
+} // namespace gymrs

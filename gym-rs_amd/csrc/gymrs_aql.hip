@@ -1,0 +1,534 @@
+// gymrs_aql.hip -- the engine's own AQL dispatcher (host code only; see gymrs_aql.h for the why and the protocol).
+// HSA next to HIP: the HIP runtime sits on the same ROCr instance, hsa_init() only takes a reference; device memory that
+// hipMalloc returned is ordinary agent memory to a kernel dispatched through an HSA queue of the same agent.
+#include "gymrs_aql.h"
+
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+// The stand-alone code object of gymrs_step_aql.hip, built by build.py right before this file and embedded here.
+__asm__(".section .rodata\n"
+        ".balign 4096\n"
+        ".global gymrs_aql_blob_begin\n"
+        "gymrs_aql_blob_begin:\n"
+        ".incbin \"" GYMRS_AQL_HSACO "\"\n"
+        ".global gymrs_aql_blob_end\n"
+        "gymrs_aql_blob_end:\n"
+        ".previous\n");
+extern "C" const char gymrs_aql_blob_begin[];
+extern "C" const char gymrs_aql_blob_end[];
+#endif
+
+namespace gymrs {
+namespace {
+
+constexpr uint32_t kQueuePackets = 4096;
+constexpr uint32_t kKernargSlots = 8 * kQueuePackets; // a slot is rewritten only after kQueuePackets later packets were CONSUMED
+constexpr uint32_t kFlushEvery = 64;
+
+const char* hsa_err(hsa_status_t s)
+{
+    const char* m = nullptr;
+    hsa_status_string(s, &m);
+    return m ? m : "HSA error";
+}
+
+#define HSA_OK(expr, what)                                                     \
+    do {                                                                       \
+        const hsa_status_t st_ = (expr);                                       \
+        if (st_ != HSA_STATUS_SUCCESS) {                                       \
+            *why = std::string(what) + ": " + hsa_err(st_);                    \
+            return false;                                                      \
+        }                                                                      \
+    } while (0)
+#define HIP_OK(expr, what)                                                     \
+    do {                                                                       \
+        const hipError_t e_ = (expr);                                          \
+        if (e_ != hipSuccess) {                                                \
+            *why = std::string(what) + ": " + hipGetErrorString(e_);          \
+            return false;                                                      \
+        }                                                                      \
+    } while (0)
+
+struct DeviceCtx {
+    bool tried = false, ok = false;
+    std::string why;
+    hsa_agent_t gpu{}, cpu{};
+    hsa_amd_memory_pool_t gpu_pool{};
+    hsa_executable_t exe{};
+    std::map<std::string, AqlKernel> kernels;
+};
+
+constexpr int kMaxDevices = 64;
+DeviceCtx g_ctx[kMaxDevices];
+std::mutex g_mu;
+
+struct FindAgents {
+    uint32_t want_bdf = 0, want_domain = 0;
+    hsa_agent_t gpu{}, cpu{};
+};
+
+hsa_status_t on_agent(hsa_agent_t a, void* data)
+{
+    auto* f = static_cast<FindAgents*>(data);
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_CPU && f->cpu.handle == 0) f->cpu = a;
+    if (t == HSA_DEVICE_TYPE_GPU) {
+        uint32_t bdf = 0, domain = 0;
+        hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf);
+        hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &domain);
+        if (bdf == f->want_bdf && domain == f->want_domain) f->gpu = a;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+
+hsa_status_t on_gpu_pool(hsa_amd_memory_pool_t p, void* data)
+{
+    auto* out = static_cast<hsa_amd_memory_pool_t*>(data);
+    hsa_amd_segment_t seg;
+    uint32_t flags = 0;
+    bool alloc = false;
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg);
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    hsa_amd_memory_pool_get_info(p, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (seg == HSA_AMD_SEGMENT_GLOBAL && alloc && (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED) && out->handle == 0) *out = p;
+    return HSA_STATUS_SUCCESS;
+}
+
+uint16_t packet_header(int acquire, int release)
+{
+    return (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                      (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE));
+}
+
+void queue_error(hsa_status_t status, hsa_queue_t*, void* data)
+{
+    if (data) static_cast<std::atomic<int>*>(data)->store((int)status ? (int)status : -1);
+    std::fprintf(stderr, "gymrs: AQL queue error: %s\n", hsa_err(status));
+}
+
+} // namespace
+
+class AqlChain {
+public:
+    DeviceCtx* ctx = nullptr;
+    int device = 0;
+    hsa_queue_t* q = nullptr;
+    char* kernarg = nullptr;     // device memory, written by the CPU through the PCIe BAR
+    uint32_t* in_flag = nullptr; // device word the HIP stream writes (hipStreamWriteValue32), the chain's first packet waits for
+    uint32_t* out_flag = nullptr; // signal memory the chain's last packet writes, the HIP stream waits for (hipStreamWaitValue32)
+    uint32_t* host_err = nullptr; // mapped host word: a wait that gave up
+    uint32_t* host_err_dev = nullptr;
+    uint32_t seq = 0;
+    bool in_chain = false;
+    bool lazy_pending = false;
+    std::atomic<int> queue_status{0};
+    AqlKernel k_wait, k_set;
+    // packets written but not yet published (headers still INVALID)
+    struct Staged {
+        hsa_kernel_dispatch_packet_t* p;
+        uint32_t header_and_setup;
+        uint64_t idx;
+    };
+    std::vector<Staged> staged;
+    void* last_kernarg = nullptr;
+
+    bool stage(const AqlKernel& k, uint32_t grid_workitems, uint32_t wg, const void* args, size_t bytes, int acquire, int release, hsa_signal_t completion,
+               std::string* why)
+    {
+        if (queue_status.load() != 0) {
+            *why = "the AQL queue reported an error earlier";
+            return false;
+        }
+        if (bytes > kAqlKernargSlot) {
+            *why = "kernel arguments larger than a ring slot";
+            return false;
+        }
+        const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
+        if (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {
+            publish(); // whatever is staged has to become visible before the queue can drain
+            const auto t0 = std::chrono::steady_clock::now();
+            while (idx - hsa_queue_load_read_index_scacquire(q) >= q->size) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    *why = "the AQL queue did not drain within 20 s";
+                    return false;
+                }
+            }
+        }
+        char* slot = kernarg + (size_t)(idx % kKernargSlots) * kAqlKernargSlot;
+        std::memcpy(slot, args, bytes);
+        last_kernarg = slot;
+        auto* p = &static_cast<hsa_kernel_dispatch_packet_t*>(q->base_address)[idx & (q->size - 1)];
+        const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        // the slot may still carry the header of the packet that used it a lap ago: no valid header over a half-written body
+        __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)(HSA_PACKET_TYPE_INVALID << HSA_PACKET_HEADER_TYPE), __ATOMIC_RELAXED);
+        p->workgroup_size_x = (uint16_t)wg;
+        p->workgroup_size_y = p->workgroup_size_z = 1;
+        p->reserved0 = 0;
+        p->grid_size_x = grid_workitems;
+        p->grid_size_y = p->grid_size_z = 1;
+        p->private_segment_size = k.private_bytes;
+        p->group_segment_size = k.group_bytes;
+        p->kernel_object = k.object;
+        p->kernarg_address = slot;
+        p->reserved2 = 0;
+        p->completion_signal = completion;
+        staged.push_back({p, (uint32_t)packet_header(acquire, release) | ((uint32_t)setup << 16), idx});
+        // (developer knob for A/B runs: packets per publish)
+        static const size_t flush_every = [] { const char* v = std::getenv("GYMRS_AQL_FLUSH"); return v ? (size_t)std::strtoul(v, nullptr, 0) : (size_t)kFlushEvery; }();
+        if (staged.size() >= flush_every) publish();
+        return true;
+    }
+
+    // Make the staged packets visible to the packet processor: first the kernel arguments (write-combined stores through the
+    // BAR: drain them and read one back, so that they HAVE landed in device memory), then the headers, then the doorbell.
+    void publish()
+    {
+        if (staged.empty()) return;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        _mm_sfence();
+#endif
+        if (last_kernarg) (void)*static_cast<volatile uint32_t*>(last_kernarg);
+        for (const Staged& s : staged) __atomic_store_n(reinterpret_cast<uint32_t*>(s.p), s.header_and_setup, __ATOMIC_RELEASE);
+        hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)staged.back().idx);
+        staged.clear();
+    }
+};
+
+namespace {
+
+bool load_code(DeviceCtx* c, std::string* why)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    const size_t bytes = (size_t)(gymrs_aql_blob_end - gymrs_aql_blob_begin);
+    hsa_code_object_reader_t reader;
+    HSA_OK(hsa_code_object_reader_create_from_memory(gymrs_aql_blob_begin, bytes, &reader), "code object reader");
+    HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe), "hsa_executable_create_alt");
+    HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
+    HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
+    static const char* names[] = {"gymrs_aql_cartpole_t512_nt", "gymrs_aql_cartpole_t512_pl", "gymrs_aql_cartpole_t256_nt", "gymrs_aql_cartpole_t256_pl",
+                                  "gymrs_aql_mountain_car_t256_nt", "gymrs_aql_mountain_car_t256_pl", "gymrs_aql_pendulum_t256_nt",
+                                  "gymrs_aql_pendulum_t256_pl", "gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
+    for (const char* nm : names) {
+        hsa_executable_symbol_t sym;
+        HSA_OK(hsa_executable_get_symbol_by_name(c->exe, (std::string(nm) + ".kd").c_str(), &c->gpu, &sym), nm);
+        AqlKernel k;
+        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object), nm);
+        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_bytes), nm);
+        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_bytes), nm);
+        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_bytes), nm);
+        c->kernels[nm] = k;
+    }
+    return true;
+#else
+    (void)c;
+    (void)why;
+    return false;
+#endif
+}
+
+bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why)
+{
+    static const uint32_t queue_packets = [] { const char* v = std::getenv("GYMRS_AQL_QUEUE"); return v ? (uint32_t)std::strtoul(v, nullptr, 0) : kQueuePackets; }();
+    HSA_OK(hsa_queue_create(c->gpu, queue_packets, HSA_QUEUE_TYPE_SINGLE, queue_error, &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
+    void* ka = nullptr;
+    HSA_OK(hsa_amd_memory_pool_allocate(c->gpu_pool, (size_t)kKernargSlots * kAqlKernargSlot, 0, &ka), "kernel-argument ring");
+    ch->kernarg = static_cast<char*>(ka);
+    // the CPU writes the ring through the PCIe BAR (what HIP does with its own kernel arguments on this part)
+    HSA_OK(hsa_amd_agents_allow_access(1, &c->cpu, nullptr, ka), "CPU access to device memory (large BAR)");
+    return true;
+}
+
+// The assumption the fence-free chain rests on, checked ON THIS DEVICE before the path is used: launches chained by the barrier
+// bit alone (agent acquire, NO release) see each other's stores -- with grids that are not multiples of the XCD count and with
+// one-workgroup launches in between (neither may change which XCD a workgroup index lands on).
+bool self_check(DeviceCtx* c, int device, std::string* why)
+{
+    AqlChain ch;
+    ch.ctx = c;
+    ch.device = device;
+    bool ok = false;
+    float* x = nullptr;
+    uint32_t* flag = nullptr;
+    hsa_signal_t done{};
+    constexpr uint32_t kLaunches = 96;
+    do {
+        if (!make_queue(c, &ch, why)) break;
+        const uint32_t n4 = 1021u * 256u + 77u; // 1022 workgroups: not a multiple of 8, the last one partial
+        if (hipMalloc(&x, (size_t)n4 * 16) != hipSuccess || hipMalloc(&flag, 64) != hipSuccess) {
+            *why = "self-check: hipMalloc failed";
+            break;
+        }
+        if (hipMemset(x, 0, (size_t)n4 * 16) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            *why = "self-check: hipMemset failed";
+            break;
+        }
+        if (hsa_signal_create(1, 0, nullptr, &done) != HSA_STATUS_SUCCESS) {
+            *why = "self-check: hsa_signal_create failed";
+            break;
+        }
+        struct {
+            float* x;
+            uint32_t n4;
+        } args{x, n4};
+        struct {
+            uint32_t* flag;
+            uint32_t seq;
+        } fargs{flag, 0};
+        const AqlKernel& k = c->kernels["gymrs_aql_selfcheck"];
+        const AqlKernel& ks = c->kernels["gymrs_aql_set_flag"];
+        bool staged_ok = true;
+        for (uint32_t t = 0; t < kLaunches && staged_ok; ++t) {
+            const bool last = t + 1 == kLaunches;
+            staged_ok = ch.stage(k, 1022u * 256u, 256, &args, sizeof(args), HSA_FENCE_SCOPE_AGENT, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+                                 last ? done : hsa_signal_t{0}, why);
+            if (staged_ok && !last && (t % 3) != 2) { // one-workgroup launches in between, as the ends of real chains are
+                fargs.seq = t;
+                staged_ok = ch.stage(ks, 64, 64, &fargs, sizeof(fargs), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0}, why);
+            }
+        }
+        if (!staged_ok) break;
+        ch.publish();
+        if (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, 10ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_BLOCKED) >= 1) {
+            *why = "self-check: the chain did not finish within 10 s";
+            break;
+        }
+        std::vector<float> host((size_t)n4 * 4);
+        if (hipMemcpy(host.data(), x, host.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+            *why = "self-check: hipMemcpy failed";
+            break;
+        }
+        size_t wrong = 0;
+        for (float v : host) wrong += v != (float)kLaunches;
+        if (wrong) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "self-check: %zu of %zu words lost an update in a fence-free chain of %u launches", wrong, host.size(), kLaunches);
+            *why = buf;
+            break;
+        }
+        ok = true;
+    } while (false);
+    if (done.handle) hsa_signal_destroy(done);
+    if (ch.q) hsa_queue_destroy(ch.q);
+    if (ch.kernarg) hsa_amd_memory_pool_free(ch.kernarg);
+    if (x) (void)hipFree(x);
+    if (flag) (void)hipFree(flag);
+    return ok;
+}
+
+bool init_device(DeviceCtx* c, int device, std::string* why)
+{
+    int can_wait = 0;
+    HIP_OK(hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device), "hipDeviceGetAttribute");
+    if (!can_wait) {
+        *why = "the device has no stream memory operations (hipStreamWaitValue32)";
+        return false;
+    }
+    char bus[64] = {0};
+    HIP_OK(hipDeviceGetPCIBusId(bus, sizeof(bus), device), "hipDeviceGetPCIBusId");
+    unsigned dom = 0, b = 0, d = 0, f = 0;
+    if (std::sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) != 4) {
+        *why = std::string("unparsable PCI bus id ") + bus;
+        return false;
+    }
+    HSA_OK(hsa_init(), "hsa_init");
+    FindAgents find;
+    find.want_bdf = (b << 8) | (d << 3) | f;
+    find.want_domain = dom;
+    HSA_OK(hsa_iterate_agents(on_agent, &find), "hsa_iterate_agents");
+    if (find.gpu.handle == 0 || find.cpu.handle == 0) {
+        *why = std::string("no HSA agent for HIP device at ") + bus;
+        return false;
+    }
+    c->gpu = find.gpu;
+    c->cpu = find.cpu;
+    HSA_OK(hsa_amd_agent_iterate_memory_pools(c->gpu, on_gpu_pool, &c->gpu_pool), "memory pools");
+    if (c->gpu_pool.handle == 0) {
+        *why = "no coarse-grained device memory pool";
+        return false;
+    }
+    if (!load_code(c, why)) return false;
+    return self_check(c, device, why);
+}
+
+} // namespace
+
+AqlChain* aql_create(int hip_device, std::string* why)
+{
+    std::string local;
+    if (!why) why = &local;
+    if (hip_device < 0 || hip_device >= kMaxDevices) {
+        *why = "device index out of range";
+        return nullptr;
+    }
+    DeviceCtx* c = &g_ctx[hip_device];
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (!c->tried) {
+            c->tried = true;
+            c->ok = init_device(c, hip_device, &c->why);
+        }
+        if (!c->ok) {
+            *why = c->why;
+            return nullptr;
+        }
+    }
+    AqlChain* ch = new AqlChain();
+    ch->ctx = c;
+    ch->device = hip_device;
+    ch->k_wait = c->kernels["gymrs_aql_wait_flag"];
+    ch->k_set = c->kernels["gymrs_aql_set_flag"];
+    bool ok = make_queue(c, ch, why);
+    if (ok) {
+        void* p = nullptr;
+        ok = hipMalloc(&p, 64) == hipSuccess && hipMemset(p, 0, 64) == hipSuccess;
+        ch->in_flag = static_cast<uint32_t*>(p);
+        if (!ok) *why = "hipMalloc (hand-over flag) failed";
+    }
+    if (ok) { // what hipStreamWaitValue32 can wait on: signal memory
+        void* p = nullptr;
+        ok = hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess;
+        ch->out_flag = static_cast<uint32_t*>(p);
+        if (!ok) *why = "hipExtMallocWithFlags(hipMallocSignalMemory) failed";
+    }
+    if (ok) {
+        void* p = nullptr;
+        ok = hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess;
+        ch->host_err = static_cast<uint32_t*>(p);
+        if (ok) {
+            ch->host_err[0] = 0;
+            ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&ch->host_err_dev), p, 0) == hipSuccess;
+        }
+        if (!ok) *why = "hipHostMalloc (error word) failed";
+    }
+    if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+    if (ok) { // the hand-over itself, once, on a stream of its own: begin -> end must let the stream through
+        hipStream_t probe = nullptr;
+        ok = hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) == hipSuccess;
+        if (ok) ok = hipStreamWriteValue32(probe, ch->out_flag, 0, 0) == hipSuccess && hipStreamSynchronize(probe) == hipSuccess;
+        if (!ok) *why = "initialising the hand-over flags through the stream failed";
+        if (ok) ok = aql_begin(ch, probe, why) && aql_end(ch, probe, why);
+        if (ok) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t q = hipErrorNotReady;
+            while ((q = hipStreamQuery(probe)) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) {
+            }
+            ok = q == hipSuccess && aql_take_error(ch) == 0;
+            if (!ok) *why = "hand-over self-check: the stream did not come through an empty chain within 5 s";
+        }
+        if (ok && probe) (void)hipStreamDestroy(probe); // (a stream that is stuck behind a wait is left alone)
+    }
+    if (!ok) {
+        // (a chain whose hand-over got stuck keeps its queue and flags: tearing them down under a pending wait could fault)
+        if (why->find("hand-over self-check") == std::string::npos) aql_destroy(ch);
+        return nullptr;
+    }
+    return ch;
+}
+
+void aql_destroy(AqlChain* c)
+{
+    if (!c) return;
+    if (c->q) hsa_queue_destroy(c->q);
+    if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
+    if (c->in_flag) (void)hipFree(c->in_flag);
+    if (c->out_flag) (void)hipFree(c->out_flag);
+    if (c->host_err) (void)hipHostFree(c->host_err);
+    delete c;
+}
+
+bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out)
+{
+    auto it = c->ctx->kernels.find(name);
+    if (it == c->ctx->kernels.end()) return false;
+    *out = it->second;
+    return true;
+}
+
+bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
+{
+    if (c->in_chain) {
+        *why = "aql_begin inside a chain";
+        return false;
+    }
+    c->seq += 1;
+    // behind everything enqueued on the engine's stream so far ...
+    HIP_OK(hipStreamWriteValue32(stream, c->in_flag, c->seq, 0), "hipStreamWriteValue32");
+    // ... and the chain's first packet waits for it
+    struct {
+        const uint32_t* flag;
+        uint32_t seq;
+        uint32_t pad;
+        uint32_t* err;
+    } args{c->in_flag, c->seq, 0, c->host_err_dev};
+    if (!c->stage(c->k_wait, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0}, why)) return false;
+    c->in_chain = true;
+    return true;
+}
+
+bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes, std::string* why)
+{
+    // barrier bit: after the previous packet has completed.  Agent-scope ACQUIRE (L1 and scalar caches start clean: free,
+    // measured), NO release: the lines this launch leaves dirty in an XCD's L2 are read by the next launch on that same XCD.
+    // (GYMRS_AQL_FENCES="<acquire><release>", digits 0 none / 1 agent / 2 system: developer knob for A/B runs)
+    static const int acq = [] { const char* v = std::getenv("GYMRS_AQL_FENCES"); return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : (int)HSA_FENCE_SCOPE_AGENT; }();
+    static const int rel = [] { const char* v = std::getenv("GYMRS_AQL_FENCES"); return v && v[0] && v[1] >= '0' && v[1] <= '2' ? v[1] - '0' : (int)HSA_FENCE_SCOPE_NONE; }();
+    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, rel, hsa_signal_t{0}, why);
+}
+
+bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
+{
+    if (!c->in_chain) {
+        *why = "aql_end outside a chain";
+        return false;
+    }
+    c->in_chain = false;
+    // Two packets close the chain.  The first exists for its END-OF-KERNEL system-scope release: everything the chain left
+    // dirty in the L2s is written back when it completes (its own store goes to a scratch word).  The second starts after
+    // that -- barrier bit -- and only then tells the stream to go on: a flag stored by the packet that also carries the
+    // release would become visible BEFORE the write-back it announces.
+    struct {
+        uint32_t* flag;
+        uint32_t seq;
+    } scratch{c->in_flag + 8, c->seq}, args{c->out_flag, c->seq};
+    if (!c->stage(c->k_set, 64, 64, &scratch, sizeof(scratch), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
+    if (!c->stage(c->k_set, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
+    c->publish();
+    if (std::getenv("GYMRS_AQL_LAZY_WAIT")) { // EXPERIMENT: no wait on the stream; aql_host_wait() polls from the host
+        c->lazy_pending = true;
+        return true;
+    }
+    HIP_OK(hipStreamWaitValue32(stream, c->out_flag, c->seq, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32");
+    return true;
+}
+
+void aql_host_wait(AqlChain* c)
+{
+    if (!c || !c->lazy_pending) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((int32_t)(__atomic_load_n(c->out_flag, __ATOMIC_ACQUIRE) - c->seq) < 0) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
+    }
+    c->lazy_pending = false;
+}
+
+uint32_t aql_take_error(AqlChain* c)
+{
+    const uint32_t v = c->host_err ? c->host_err[0] : 0;
+    if (v) c->host_err[0] = 0;
+    return v | (c->queue_status.load() != 0 ? 2u : 0u);
+}
+
+} // namespace gymrs

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gymrs_amd.h"
+#include "gymrs_aql.h"
 #include "gymrs_json.h"
 #include "gymrs_kernels.h"
 
@@ -147,6 +148,12 @@ struct gymrs_engine {
     uint64_t age_ref_tick = 0;          // tick the ages of the refresh in flight are measured from
     uint64_t age_next_refresh = 0;      // no new refresh before this tick (doubling back-off while the limit stays reachable)
     uint32_t age_backoff = 8;
+    // The engine's own AQL dispatcher for chains of per-step launches (gymrs_aql.h): created at the first gymrs_step_many that
+    // can use it; aql_why says why not when it stays NULL.
+    AqlChain* aql = nullptr;
+    bool aql_tried = false;
+    std::string aql_why;
+    uint64_t aql_chains = 0, aql_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t limit_elided_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t age_refreshes = 0, age_waits = 0, age_wait_ns = 0;
 };
@@ -603,6 +610,7 @@ gymrs_status gymrs_engine_destroy(gymrs_engine* e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(e->comm);
+    aql_destroy(e->aql); // (the stream is idle: every chain ended with a wait on it)
     if (e->device >= 0 && e->device < kMaxDevices) { // a later engine at the same address must not pass for this one
         const gymrs_engine* self = e;
         g_last_stepper[e->device].compare_exchange_strong(self, nullptr, std::memory_order_relaxed);
@@ -1200,6 +1208,123 @@ static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stri
     return GYMRS_OK;
 }
 
+// ---- chains of per-step launches through the engine's own AQL dispatcher (gymrs_aql.h) ---------------------------------
+// Which launches it takes: the flag sets the stand-alone code object holds (gymrs_step_aql.hip) at 4 lanes per work-item, on
+// engines whose arrays live in device memory; chains of at least kAqlMinChain steps (a chain costs three small packets and two
+// stream operations of its own).  Everything else -- and every device on which the dispatcher's self-check fails -- goes
+// through HIP launches.
+constexpr uint32_t kAqlMinChain = 8;
+
+static const char* aql_kernel_name(const gymrs_engine* e, uint32_t flags, int threads)
+{
+    const bool nt = (flags & kFlagNonTemporal) != 0;
+    constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
+    const uint32_t f = flags & (A | S | T);
+    switch (e->kind) {
+    case GYMRS_CARTPOLE:
+        if (f != (A | S)) return nullptr;
+        return threads == kCartPoleThreads ? (nt ? "gymrs_aql_cartpole_t512_nt" : "gymrs_aql_cartpole_t512_pl")
+                                           : (nt ? "gymrs_aql_cartpole_t256_nt" : "gymrs_aql_cartpole_t256_pl");
+    case GYMRS_MOUNTAIN_CAR:
+        if (f != (A | S)) return nullptr;
+        return nt ? "gymrs_aql_mountain_car_t256_nt" : "gymrs_aql_mountain_car_t256_pl";
+    case GYMRS_PENDULUM:
+        if (f != (A | S | T)) return nullptr;
+        return nt ? "gymrs_aql_pendulum_t256_nt" : "gymrs_aql_pendulum_t256_pl";
+    }
+    return nullptr;
+}
+
+static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
+{
+    if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host || e->limit_elidable) return false;
+    if (const char* v = std::getenv("GYMRS_AQL")) // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
+        if (v[0] == '0') return false;
+    if (!aql_kernel_name(e, e->flags, kBlock)) return false;
+    if (!e->own_stream) { // a caller-provided stream may be under a capture: a chain cannot be captured
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(e->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
+    }
+    if (!e->aql_tried) {
+        e->aql_tried = true;
+        e->aql = aql_create(e->device, &e->aql_why);
+    }
+    return e->aql != nullptr;
+}
+
+extern "C++" {
+template <class Consts>
+static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const StepArgs& a, const Consts& c, std::string* err)
+{
+    StepKernArgs<Consts> ka;
+    std::memset(&ka, 0, sizeof(ka));
+    ka.s0 = a.s[0];
+    ka.s1 = a.s[1];
+    ka.s2 = a.s[2];
+    ka.s3 = a.s[3];
+    ka.action = a.action;
+    ka.n_fast = a.n_fast;
+    ka.rest = a;
+    ka.c = c;
+    static_assert(sizeof(ka) <= kAqlKernargSlot, "kernel arguments larger than a ring slot");
+    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err);
+}
+} // extern "C++"
+
+// steps [first, n_steps) of a gymrs_step_many call as ONE chain.  *taken = false: nothing was dispatched, use HIP launches.
+static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t stride_bytes, uint32_t n_buffers, uint32_t first, uint32_t n_steps,
+                                  bool* taken)
+{
+    *taken = false;
+    std::string err;
+    // reset-log rows laid out for another launch shape are folded by a HIP kernel: BEFORE the chain, on the stream it waits for
+    if (e->reset_log && e->log_pending != 0 && e->log_vec != e->vec) {
+        if (gymrs_status st = fold_reset_log(e)) return st;
+    }
+    if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched: this engine goes back to HIP launches for good
+        e->aql_why = "aql_begin: " + err;
+        aql_destroy(e->aql);
+        e->aql = nullptr;
+        return GYMRS_OK;
+    }
+    *taken = true;
+    const int threads = step_threads_of(e->kind, e->n, e->vec);
+    const char* last_name = nullptr;
+    AqlKernel k;
+    auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
+        const std::string msg = g_last_error;
+        std::string ignored;
+        (void)aql_end(e->aql, e->stream, &ignored);
+        g_last_error = msg;
+        return st;
+    };
+    for (uint32_t t = first; t < n_steps; ++t) {
+        uint32_t flags = 0;
+        if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
+        StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
+        if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
+        const char* name = aql_kernel_name(e, flags, threads);
+        if (name != last_name) {
+            if (!name || !aql_kernel(e->aql, name, &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));
+            last_name = name;
+        }
+        bool ok = false;
+        switch (e->kind) {
+        case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err); break;
+        case GYMRS_MOUNTAIN_CAR: ok = aql_step(e, k, threads, a, e->consts.mc, &err); break;
+        case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err); break;
+        }
+        if (!ok) return bail(fail(GYMRS_EHIP, "AQL dispatcher: " + err));
+        e->tick += 1;
+        if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
+        if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
+        e->aql_launches += 1;
+    }
+    if (!aql_end(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
+    e->aql_chains += 1;
+    return GYMRS_OK;
+}
+
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes, uint32_t n_buffers,
                              uint32_t n_steps, int use_graph)
 {
@@ -1251,6 +1376,11 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
             if (e->flags & GYMRS_TIME_LIMIT) e->trunc_zero = false; // the replayed launches wrote the flags themselves
         }
     }
+    if (!use_graph && aql_usable(e, n_steps - done)) { // a chain through the engine's own AQL dispatcher
+        bool taken = false;
+        if (gymrs_status st = step_many_aql(e, base, stride_bytes, n_buffers, done, n_steps, &taken)) return st;
+        if (taken) done = n_steps;
+    }
     for (uint32_t t = done; t < n_steps; ++t) { // eager launches (and the remainder after graph replays)
         uint32_t flags = 0;
         if (gymrs_status st = flags_for_step(e, &flags)) return st;
@@ -1270,7 +1400,14 @@ gymrs_status gymrs_sync(gymrs_engine* e)
     if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    aql_host_wait(e->aql);
     std::atomic_thread_fence(std::memory_order_acquire);
+    if (e->aql) {
+        if (const uint32_t bad = aql_take_error(e->aql))
+            return fail(GYMRS_EHIP, (bad & 2u) ? "the AQL queue reported an error"
+                                               : "a gymrs_step_many chain ran without waiting for the engine's stream: the stream did not reach "
+                                                 "the hand-over point within ~2 s (is it blocked on work that was never submitted?)");
+    }
     if (*e->err_seen == 0) return GYMRS_OK; // no kernel saw an invalid action: nothing to fetch
     uint32_t err[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(err, e->err, sizeof(err), hipMemcpyDeviceToHost, e->stream));
@@ -1774,6 +1911,9 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
     g.str("kind", e->kind == GYMRS_CARTPOLE ? "CartPole" : (e->kind == GYMRS_MOUNTAIN_CAR ? "MountainCar" : "Pendulum"));
     g.uint("n_envs", e->n).uint("global_env_id", e->gid0 + lane).uint("flags", e->flags).uint("seed", e->seed).uint("tick", e->tick);
     g.uint("max_episode_steps", max_episode_steps);
+    // chains of per-step launches that went through the engine's own AQL dispatcher (gymrs_aql.h), and why not if none can
+    g.uint("aql_chains", e->aql_chains).uint("aql_launches", e->aql_launches);
+    g.str("aql", e->aql ? "on" : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
     if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
         g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
         g.uint("time_limit_waits", e->age_waits).uint("time_limit_wait_us", e->age_wait_ns / 1000);

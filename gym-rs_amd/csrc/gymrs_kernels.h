@@ -52,6 +52,20 @@ struct StepArgs {
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
 };
 
+// The kernel-argument segment of step_kernel as the host sees it (the engine's own AQL dispatcher, gymrs_aql.h, fills it by
+// hand; HIP launches marshal the same thing themselves): the parameters in order, naturally aligned.
+template <class Consts>
+struct StepKernArgs {
+    float* s0;
+    float* s1;
+    float* s2;
+    float* s3;
+    const void* action;
+    uint64_t n_fast;
+    StepArgs rest;
+    Consts c;
+};
+
 // The fused multi-step kernel (gymrs_rollout): n_steps consecutive steps of every lane in ONE launch, with
 // the random-policy actions of gymrs_fill_actions(action_seed, action_t0 + k) generated in registers.
 struct RolloutArgs {
@@ -86,6 +100,16 @@ struct ResetArgs {
     const uint64_t* pcg_seeds;
     double pcg_low[4], pcg_scale[4];
 };
+
+// Work-items per workgroup of a per-step launch: CartPole uses 512 once the launch still puts two such workgroups on every
+// CU (measured 2 % faster there; small batches want many small workgroups), everything else kBlock.  launch_one
+// (gymrs_step_impl.h) and the engine's AQL dispatcher both go by this.
+constexpr int kCartPoleThreads = 512;
+constexpr uint64_t kBigGroupsFrom = 512;
+inline int step_threads_of(gymrs_env_kind kind, uint64_t n, int vec)
+{
+    return (kind == GYMRS_CARTPOLE && n >= (uint64_t)kCartPoleThreads * vec * kBigGroupsFrom) ? kCartPoleThreads : kBlock;
+}
 
 // Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4 or 8).
 inline uint32_t step_grid(uint64_t n, int vec, int threads = kBlock)

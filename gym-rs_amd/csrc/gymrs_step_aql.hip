@@ -1,0 +1,68 @@
+// gymrs_step_aql.hip -- the per-step kernels once more, as a STAND-ALONE gfx950 code object with plain C names
+// (hipcc --cuda-device-only --no-gpu-bundle-output -> gymrs_aql_kernels.hsaco, embedded into the library by gymrs_aql.cpp).
+// The engine's own AQL dispatcher (gymrs_aql.h) loads it through HSA and writes the dispatch packets itself: the HIP
+// runtime puts an agent-scope RELEASE fence (an L2 write-back) on every launch, which costs a back-to-back chain of
+// 2^20-lane steps 1.6-1.9 us per launch (profiles/r03_aql_probe.log); a chain of gymrs_step_many launches needs that fence
+// only on its last one -- tile i is stepped by workgroup i, hence by the same XCD and the same L2, in every launch.
+// Same templates, same flags, same code as the kernels HIP launches (gymrs_step_<env>.hip): same bits.
+// Only the flag sets the BASELINE configs run (lanes-per-work-item 4; CartPole / MountainCar AUTO_RESET|TRACK_STATS, Pendulum
+// + TIME_LIMIT; hinted and plain accesses); every other launch goes through HIP as before.
+#include "gymrs_step_impl.h"
+
+using namespace gymrs;
+
+#define GYMRS_AQL_STEP(NAME_, ENV_, FLAGS_, THREADS_)                                                                                     \
+    extern "C" GYMRS_STEP_KERNEL_ATTRS(THREADS_, 4) void NAME_(float* s0, float* s1, float* s2, float* s3, const void* action,           \
+                                                              uint64_t n_fast, const StepArgs rest, const ENV_::Consts c)               \
+    {                                                                                                                                     \
+        step_kernel_body<ENV_, 4, FLAGS_, THREADS_>(s0, s1, s2, s3, action, n_fast, rest, c);                                             \
+    }
+
+constexpr uint32_t kAS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, kAST = kAS | GYMRS_TIME_LIMIT, kNT = kFlagNonTemporal;
+GYMRS_AQL_STEP(gymrs_aql_cartpole_t512_nt, CartPoleT, kAS | kNT, 512)
+GYMRS_AQL_STEP(gymrs_aql_cartpole_t512_pl, CartPoleT, kAS, 512)
+GYMRS_AQL_STEP(gymrs_aql_cartpole_t256_nt, CartPoleT, kAS | kNT, 256)
+GYMRS_AQL_STEP(gymrs_aql_cartpole_t256_pl, CartPoleT, kAS, 256)
+GYMRS_AQL_STEP(gymrs_aql_mountain_car_t256_nt, MountainCarT, kAS | kNT, 256)
+GYMRS_AQL_STEP(gymrs_aql_mountain_car_t256_pl, MountainCarT, kAS, 256)
+GYMRS_AQL_STEP(gymrs_aql_pendulum_t256_nt, PendulumT, kAST | kNT, 256)
+GYMRS_AQL_STEP(gymrs_aql_pendulum_t256_pl, PendulumT, kAST, 256)
+
+// ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
+// First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put
+// behind everything that was enqueued there before (flag >= seq, wrap-around safe).  Bounded: a stream that never gets
+// there (blocked on work nobody submits) must not hang the queue -- the wait gives up after ~2 s of polling, sets err[0] and
+// lets the chain run (gymrs_sync reports it).
+extern "C" __global__ __launch_bounds__(64) void gymrs_aql_wait_flag(const uint32_t* flag, uint32_t seq, uint32_t* err)
+{
+    if (threadIdx.x != 0) return;
+    for (uint32_t spins = 0; spins < (1u << 21); ++spins) { // ~1 us per poll
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - seq) >= 0) {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Last packet of a chain (dispatched with a system-scope release: everything the chain wrote is written back first): tells
+// the HIP stream, which waits there with hipStreamWaitValue32, that the chain is done.
+extern "C" __global__ __launch_bounds__(64) void gymrs_aql_set_flag(uint32_t* flag, uint32_t seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- self-check of the assumption the fence-free chain rests on ---------------------------------------------------------
+// Every work-item adds 1 to its own 16 bytes; launched as a chain WITHOUT release fences, with one-workgroup launches in
+// between (they must not shift which XCD gets which workgroup) -- after K launches every word must read K.
+extern "C" __global__ __launch_bounds__(256) void gymrs_aql_selfcheck(float* x, uint32_t n4)
+{
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n4) return;
+    f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(x) + i);
+    v += 1.0f;
+    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(x) + i);
+}

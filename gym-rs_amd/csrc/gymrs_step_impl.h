@@ -158,9 +158,8 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
 // THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
 template <class Env, int VEC, uint32_t FLAGS, int THREADS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 / VEC < 1 ? 1 : 16 / VEC))) void step_kernel(
-    float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs rest,
-    const typename Env::Consts c)
+__device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs& rest,
+                                                 const typename Env::Consts& c)
 {
     constexpr int LPB = THREADS * VEC;
     __shared__ ResetLds<Env, VEC, THREADS> lds;
@@ -180,13 +179,26 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(1, 16 /
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
 }
 
+#define GYMRS_STEP_KERNEL_ATTRS(THREADS_, VEC_) \
+    __global__ __launch_bounds__(THREADS_) __attribute__((amdgpu_waves_per_eu(1, 16 / (VEC_) < 1 ? 1 : 16 / (VEC_))))
+
+template <class Env, int VEC, uint32_t FLAGS, int THREADS>
+GYMRS_STEP_KERNEL_ATTRS(THREADS, VEC) void step_kernel(float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast,
+                                                       const StepArgs rest, const typename Env::Consts c)
+{
+    step_kernel_body<Env, VEC, FLAGS, THREADS>(s0, s1, s2, s3, action, n_fast, rest, c);
+}
+
+static_assert(CartPoleT::kThreads == kCartPoleThreads && MountainCarT::kThreads == kBlock && PendulumT::kThreads == kBlock,
+              "step_threads_of (gymrs_kernels.h) must pick what launch_one picks");
+
 // ---------------------------------------------------------------------------------------------
 // launch tables
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
     if constexpr (Env::kThreads != kBlock) {
-        if (a.n >= (uint64_t)Env::kThreads * VEC * 512) { // >= 2 big workgroups per CU
+        if (a.n >= (uint64_t)Env::kThreads * VEC * kBigGroupsFrom) { // >= 2 big workgroups per CU
             hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
                                stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();

@@ -1,0 +1,201 @@
+"""gymrs_step_many through the engine's own AQL dispatcher (gym-rs_amd/csrc/gymrs_aql.h): chains of per-step launches written
+straight into an HSA queue, with the agent-scope release fence the HIP runtime puts on every launch only at the END of the
+chain.  It is another SUBMISSION PATH for the same kernels, so everything must stay bit for bit what HIP launches produce
+(GYMRS_AQL=0) and what the CPU f32 twin computes: states, rewards, flags, statistics -- at ragged and full sizes, with HIP
+work on the engine's stream right before a chain (the hand-over into the chain) and right after it (the hand-over back:
+the chain's stores must be visible to a copy, a statistics kernel, a HIP-launched step)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.bindings import TwinEngine
+
+pytestmark = pytest.mark.gpu
+
+
+class aql:
+    """GYMRS_AQL for the calls inside the block (the library looks it up per gymrs_step_many call)."""
+
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.before = os.environ.get("GYMRS_AQL")
+        os.environ["GYMRS_AQL"] = "1" if self.on else "0"
+
+    def __exit__(self, *exc):
+        if self.before is None:
+            os.environ.pop("GYMRS_AQL", None)
+        else:
+            os.environ["GYMRS_AQL"] = self.before
+
+
+def extras(eng):
+    return json.loads(eng.env_json(0))["gymrs"]
+
+
+def ring_for(eng, kind, n, nbuf, seed=5):
+    ring = torch.empty((nbuf, n), dtype=torch.float32 if kind == 2 else torch.uint8, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(ring[b].data_ptr(), seed=seed, t=b)
+    return ring  # NOT synchronised: the chain has to wait for these kernels itself
+
+
+def flags_of(gymrs, kind):
+    return gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if kind == 2 else 0)
+
+
+def same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("n", [4099, 1 << 16])
+def test_chain_equals_hip_launches_and_the_twin(gymrs, twin, kind, n):
+    nbuf, steps = 5, 67
+    flags = flags_of(gymrs, kind)
+    engines = {}
+    for on in (True, False):
+        with aql(on):
+            eng = gymrs.BatchedEngine(kind, n, flags=flags, global_env_offset=12345)
+            eng.reset(seed=9)
+            ring = ring_for(eng, kind, n, nbuf)
+            eng.step_many(ring.data_ptr(), ring.stride(0) * ring.element_size(), nbuf, steps)  # no sync before: fills -> chain
+            # no sync after either: the copies below ride the engine's stream, behind the chain's hand-over
+            engines[on] = (eng, eng.get_state(), eng.get_step_result(), eng.get_obs(), eng.stats(), ring)
+    e_on, e_off = engines[True][0], engines[False][0]
+    x_on, x_off = extras(e_on), extras(e_off)
+    assert x_on["aql"] == "on" and x_on["aql_launches"] == steps and x_on["aql_chains"] == 1, x_on
+    assert x_off["aql_launches"] == 0
+    for i in (1, 3):
+        assert same(engines[True][i], engines[False][i])
+    r_on, r_off = engines[True][2], engines[False][2]
+    assert same(r_on[0], r_off[0]) and np.array_equal(r_on[1], r_off[1]) and np.array_equal(r_on[2], r_off[2])
+    assert np.array_equal(engines[True][4], engines[False][4])
+    # and the twin
+    tw = TwinEngine(twin, kind, n, e_on.params, flags=flags, gid0=12345)
+    tw.reset(9)
+    bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+    for t in range(steps):
+        tw.step(bufs[t % nbuf])
+    assert same(engines[True][1], tw.get_state()) and np.array_equal(engines[True][4], tw.stats())
+    assert np.array_equal(r_on[1], tw.get_result()[1])
+    for e in (e_on, e_off):
+        e.close()
+
+
+def test_chains_interleaved_with_hip_launches_statistics_and_copies(gymrs, twin):
+    """chain -> gymrs_step (HIP) -> statistics -> chain -> set_state -> chain -> clone -> chain on both: every boundary between
+    the two submission paths, at a size whose reset-log ring is folded inside chains and by the stand-alone kernel."""
+    kind, n, nbuf = 0, 70_001, 8
+    flags = flags_of(gymrs, kind)
+    with aql(True):
+        eng = gymrs.BatchedEngine(kind, n, flags=flags)
+        tw = TwinEngine(twin, kind, n, eng.params, flags=flags)
+        eng.reset(seed=3)
+        tw.reset(3)
+        ring = ring_for(eng, kind, n, nbuf)
+        bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+        stride = ring.stride(0)
+        t_dev = 0
+
+        def both(k):
+            nonlocal t_dev
+            eng.step_many(ring.data_ptr(), stride, nbuf, k)
+            for t in range(k):
+                tw.step(bufs[t % nbuf])
+            t_dev += k
+
+        both(13)                                # a chain that ends in mid-ring (5 rows pending)
+        eng.step(ring[0].data_ptr())            # one HIP launch right behind it
+        tw.step(bufs[0])
+        assert np.array_equal(eng.stats(), tw.stats())   # folds the pending rows with the stand-alone kernel
+        both(40)
+        assert same(eng.get_state(), tw.get_state())
+        st = eng.get_state()
+        st[:, :100] = 0.01
+        eng.set_state(st)
+        tw.set_state(st)
+        both(9)
+        twin_clone_state = tw.get_state().copy()
+        clone = eng.clone()
+        both(24)
+        clone.step_many(ring.data_ptr(), stride, nbuf, 24)   # the clone builds its own chain object
+        assert same(clone.get_state(), eng.get_state()) and np.array_equal(clone.stats(), eng.stats())
+        assert same(eng.get_state(), tw.get_state()) and np.array_equal(eng.stats(), tw.stats())
+        assert not same(twin_clone_state, tw.get_state())
+        x = extras(eng)
+        assert x["aql"] == "on" and x["aql_chains"] == 4 and x["aql_launches"] == 13 + 40 + 9 + 24
+        assert extras(clone)["aql_chains"] == 1
+        clone.close()
+        eng.close()
+
+
+def test_short_calls_and_other_flag_sets_keep_to_hip_launches(gymrs):
+    n = 5000
+    with aql(True):
+        with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS) as eng:
+            eng.reset(seed=1)
+            ring = ring_for(eng, 0, n, 4)
+            eng.step_many(ring.data_ptr(), n, 4, 3)      # shorter than a chain is worth
+            assert extras(eng)["aql_launches"] == 0
+            eng.step_many(ring.data_ptr(), n, 4, 40, use_graph=True)   # graph replays are HIP's
+            assert extras(eng)["aql_launches"] == 0
+        with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET) as eng:   # a flag set the stand-alone code object does not hold
+            eng.reset(seed=1)
+            ring = ring_for(eng, 0, n, 4)
+            eng.step_many(ring.data_ptr(), n, 4, 40)
+            assert extras(eng)["aql_launches"] == 0
+        with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS, lanes_per_thread=8) as eng:
+            eng.reset(seed=1)
+            ring = ring_for(eng, 0, n, 4)
+            eng.step_many(ring.data_ptr(), n, 4, 40)
+            assert extras(eng)["aql_launches"] == 0
+
+
+def test_invalid_action_inside_a_chain_is_reported(gymrs):
+    n = 10_000
+    with aql(True):
+        with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS) as eng:
+            eng.reset(seed=1)
+            ring = ring_for(eng, 0, n, 4)
+            torch.cuda.synchronize()
+            ring[2, 777] = 9
+            torch.cuda.synchronize()
+            eng.step_many(ring.data_ptr(), n, 4, 16)
+            with pytest.raises(gymrs.GymrsError, match="invalid action"):
+                eng.sync()
+            assert extras(eng)["aql_launches"] == 16
+
+
+def test_full_size_chain_is_bit_identical_and_faster(gymrs):
+    """2^20 lanes (BASELINE configs[1]): 1000-step chains against 1000 HIP launches -- same bits, same statistics; and the
+    reason the path exists: the chain is faster (the HIP runtime's per-launch release fence costs this kernel > 1 us)."""
+    n, nbuf, steps = 1 << 20, 32, 1000
+    flags = flags_of(gymrs, 0)
+    out = {}
+    for on in (True, False):
+        with aql(on):
+            eng = gymrs.BatchedEngine(0, n, flags=flags)
+            eng.reset(seed=0)
+            ring = ring_for(eng, 0, n, nbuf, seed=1)
+            eng.step_many(ring.data_ptr(), n, nbuf, 300)
+            eng.sync()
+            stream = torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", 0))
+            times = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                eng.step_many(ring.data_ptr(), n, nbuf, steps)
+                e1.record(stream)
+                eng.sync()
+                times.append(e0.elapsed_time(e1) * 1e3 / steps)
+            out[on] = (eng.get_state(), eng.stats(), sorted(times)[2], extras(eng))
+            eng.close()
+    assert same(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
+    assert out[True][3]["aql_launches"] == 300 + 5 * steps and out[False][3]["aql_launches"] == 0
+    print(f"us per 2^20-lane step: AQL chain {out[True][2]:.3f}, HIP launches {out[False][2]:.3f}")
+    assert out[True][2] < out[False][2]

@@ -14,6 +14,9 @@ struct Args {
     uint32_t alu;     // dependent FMAs per lane between the loads and the stores
     uint32_t versioned;
     uint32_t pad;
+#ifdef FAT_ARGS
+    uint32_t fat[66]; // 264 more bytes of kernel arguments (the step kernel's StepArgs), all of them read by every wave
+#endif
 };
 
 extern "C" __global__ void empty_kernel(Args) {}
@@ -45,6 +48,19 @@ extern "C" __global__ __launch_bounds__(512) void stepish_kernel(Args a)
     const uint32_t act = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(a.a) + i);
     f4 y = x1;
     for (uint32_t k = 0; k < a.alu; ++k) y = y * 0.999f + x2 * 0.001f;
+#ifdef FAT_ARGS
+    {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < 66; ++k) sum += a.fat[k];
+        y += (float)sum; // (the host passes zeros)
+    }
+#endif
+#ifdef FAT_CODE
+    // ~10 KB of straight-line code every wave runs through (the step kernel is about that long)
+#pragma unroll
+    for (int k = 0; k < FAT_CODE; ++k) y = y * (1.0f + 1e-7f * (float)(k & 15)) + x2 * 1e-9f;
+#endif
     x0 += 1.0f;
     x1 = y;
     __builtin_nontemporal_store(x0, reinterpret_cast<f4*>(a.s[0]) + i);

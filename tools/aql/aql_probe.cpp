@@ -44,6 +44,9 @@ struct Args {
     uint32_t* ver;
     uint32_t* err;
     uint32_t t, alu, versioned, pad;
+#ifdef FAT_ARGS
+    uint32_t fat[66];
+#endif
 };
 
 static hsa_agent_t g_gpu, g_cpu;
@@ -151,7 +154,10 @@ int main(int argc, char** argv)
     const Kernel k_empty = find_kernel(exe, "empty_kernel.kd"), k_step = find_kernel(exe, "stepish_kernel.kd");
 
     hsa_queue_t* q = nullptr;
-    CHECK(hsa_queue_create(g_gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &q));
+    const bool multi = std::getenv("AQL_QUEUE_MULTI") != nullptr, zero_hints = std::getenv("AQL_ZERO_HINTS") != nullptr;
+    CHECK(hsa_queue_create(g_gpu, 4096, multi ? HSA_QUEUE_TYPE_MULTI : HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, zero_hints ? 0 : UINT32_MAX,
+                           zero_hints ? 0 : UINT32_MAX, &q));
+    if (std::getenv("AQL_PROFILING")) CHECK(hsa_amd_profiling_set_profiler_enabled(q, 1));
     hsa_signal_t done;
     CHECK(hsa_signal_create(1, 0, nullptr, &done));
 
@@ -171,13 +177,17 @@ int main(int argc, char** argv)
     // HIP_FORCE_DEV_KERNARG): with the ring in host memory every scalar cache fetches its copy of the arguments over PCIe and
     // a 2^20-lane launch takes 28 us instead of 5.5 (the first version of this probe, profiles/r03_aql_probe_host_kernarg.log).
     const bool host_kernarg = std::getenv("AQL_HOST_KERNARG") != nullptr;
+    // AQL_PREFILLED_KERNARG: device memory WITHOUT a CPU mapping, all slots filled up front by hsa_memory_copy (the launch number
+    // `t` then repeats every 4096 launches, so only the unversioned variants are meaningful)
+    const bool prefilled = std::getenv("AQL_PREFILLED_KERNARG") != nullptr;
     Args* kernargs = nullptr;
     if (host_kernarg) {
         kernargs = (Args*)host_alloc(g_kernarg_pool, sizeof(Args) * 4096 + 4096);
     } else {
         kernargs = (Args*)gpu_alloc(sizeof(Args) * 4096 + 4096);
-        CHECK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, kernargs));
+        if (!prefilled) CHECK(hsa_amd_agents_allow_access(1, &g_cpu, nullptr, kernargs));
     }
+    std::vector<Args> host_args(4096);
     auto fill = [&](void* dst, const void* src, size_t bytes) { CHECK(hsa_memory_copy(dst, src, bytes)); };
 
     std::printf("# agent %s, %zu lanes (%zu waves), %u launches per variant; %zu B read + %zu B written per launch\n", name, n, waves, launches,
@@ -188,6 +198,10 @@ int main(int argc, char** argv)
     std::vector<hsa_signal_t> ring_sig(256);
     for (auto& sg : ring_sig) CHECK(hsa_signal_create((hsa_signal_value_t)1 << 40, 0, nullptr, &sg));
     bool sig_every = false;
+    struct Pend { hsa_kernel_dispatch_packet_t* p; uint32_t h; uint64_t idx; };
+    std::vector<Pend> pending;
+    const size_t batch = std::getenv("AQL_BATCH") ? std::strtoul(std::getenv("AQL_BATCH"), nullptr, 0) : 1;
+    const uint64_t depth = std::getenv("AQL_DEPTH") ? std::strtoul(std::getenv("AQL_DEPTH"), nullptr, 0) : 0;
     auto run = [&](const char* label, const Kernel& k, bool barrier, uint32_t versioned, uint32_t alu, int acquire, int release) {
         double best = 1e30, sum = 0;
         std::string check = "-";
@@ -197,6 +211,15 @@ int main(int argc, char** argv)
             fill((void*)base.a, zeros.data(), n);
             err_host[0] = err_host[1] = 0;
             hsa_signal_store_relaxed(done, 1);
+            if (prefilled) {
+                for (uint32_t i = 0; i < 4096; ++i) {
+                    host_args[i] = base;
+                    host_args[i].t = i;
+                    host_args[i].alu = alu;
+                    host_args[i].versioned = versioned;
+                }
+                fill(kernargs, host_args.data(), sizeof(Args) * 4096);
+            }
             const auto t0 = std::chrono::steady_clock::now();
             for (uint32_t t = 0; t < launches; ++t) {
                 const uint64_t idx = hsa_queue_add_write_index_relaxed(q, 1);
@@ -207,8 +230,8 @@ int main(int argc, char** argv)
                 tmp.t = t;
                 tmp.alu = alu;
                 tmp.versioned = versioned;
-                std::memcpy((void*)ka, &tmp, sizeof(tmp));
-                if (!host_kernarg) { // write-combined BAR stores: drain them, then make sure they have landed before the doorbell rings
+                if (!prefilled) std::memcpy((void*)ka, &tmp, sizeof(tmp));
+                if (!host_kernarg && !prefilled) { // write-combined BAR stores: drain them, then make sure they have landed before the doorbell rings
                     _mm_sfence();
                     (void)*(volatile uint32_t*)&ka->pad;
                 }
@@ -227,8 +250,19 @@ int main(int argc, char** argv)
                 p->completion_signal = last ? done : (sig_every ? ring_sig[idx & 255] : hsa_signal_t{0});
                 // the LAST packet always carries the barrier bit and a system-scope release: its completion = everything is done
                 const uint16_t h = last ? header(true, acquire, HSA_FENCE_SCOPE_SYSTEM) : header(barrier, acquire, release);
-                __atomic_store_n((uint32_t*)p, (uint32_t)h | ((uint32_t)p->setup << 16), __ATOMIC_RELEASE);
-                hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+                if (batch <= 1) {
+                    __atomic_store_n((uint32_t*)p, (uint32_t)h | ((uint32_t)p->setup << 16), __ATOMIC_RELEASE);
+                    hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)idx);
+                } else { // the engine's dispatcher: headers and ONE doorbell per `batch` packets
+                    pending.push_back({p, (uint32_t)h | ((uint32_t)p->setup << 16), idx});
+                    if (pending.size() >= batch || last) {
+                        for (auto& pd : pending) __atomic_store_n((uint32_t*)pd.p, pd.h, __ATOMIC_RELEASE);
+                        hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)pending.back().idx);
+                        pending.clear();
+                    }
+                }
+                while (depth && idx - hsa_queue_load_read_index_scacquire(q) >= depth) { // pace the host like a slow launcher
+                }
             }
             while (hsa_signal_wait_scacquire(done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) >= 1) {
             }
@@ -266,8 +300,15 @@ int main(int argc, char** argv)
         run(l, k_step, true, 0, alu, NONE, NONE);
         std::snprintf(l, sizeof(l), "stepish alu=%u, barrier, agent fences", alu);
         run(l, k_step, true, 0, alu, AGENT, AGENT);
+        std::snprintf(l, sizeof(l), "stepish alu=%u, barrier, agent ACQUIRE only", alu);
+        run(l, k_step, true, 0, alu, AGENT, NONE);
+        std::snprintf(l, sizeof(l), "stepish alu=%u, barrier, agent RELEASE only", alu);
+        run(l, k_step, true, 0, alu, NONE, AGENT);
+        std::snprintf(l, sizeof(l), "stepish alu=%u, barrier, system fences", alu);
+        run(l, k_step, true, 0, alu, HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_SYSTEM);
         std::snprintf(l, sizeof(l), "stepish alu=%u, free, RACY (timing only)", alu);
         run(l, k_step, false, 0, alu, NONE, NONE);
+        if (!std::getenv("AQL_VERSION_WORDS")) continue;
         std::snprintf(l, sizeof(l), "stepish alu=%u, free + version words (1)", alu);
         run(l, k_step, false, 1, alu, NONE, NONE);
         std::snprintf(l, sizeof(l), "stepish alu=%u, free + version words (2)", alu);

@@ -11,6 +11,7 @@ import argparse
 import ctypes as C
 import statistics
 import sys
+import time
 from pathlib import Path
 
 import torch
@@ -51,6 +52,8 @@ def main():
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--engine-first", type=int, default=0, help="create the engines before the action ring is allocated")
     ap.add_argument("--ring-2d", type=int, default=0)
+    ap.add_argument("--wall", type=int, default=0, help="host wall clock (call + sync) instead of stream events")
+    ap.add_argument("--all", type=int, default=0, help="print every repetition")
     ap.add_argument("--nbuf", type=int, default=32, help="action buffers in the ring (32 = bench.py's default)")
     args = ap.parse_args()
     libs = [Lib(p) for p in (args.lib or [ROOT / "gym-rs_amd" / "libgymrs_amd.so"])]
@@ -81,6 +84,7 @@ def main():
         lb.ck(lb.lib.gymrs_get_stream(h, C.byref(s)))
         engines.append((lb, h, torch.cuda.ExternalStream(s.value, device="cuda:0")))
     times = {lb.path: [] for lb in libs}
+    host = {lb.path: [] for lb in libs}
     for lb, h, st in engines:  # warm-up (clocks, caches)
         lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, 2000, args.graph))
         lb.ck(lb.lib.gymrs_sync(h))
@@ -88,12 +92,18 @@ def main():
         for lb, h, st in engines:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
+            w0 = time.perf_counter()
             lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, args.steps, args.graph))
+            host[lb.path].append((time.perf_counter() - w0) * 1e6 / args.steps)
             e1.record(st)
             lb.ck(lb.lib.gymrs_sync(h))
-            times[lb.path].append(e0.elapsed_time(e1) * 1e3 / args.steps)
+            wall = (time.perf_counter() - w0) * 1e6 / args.steps
+            times[lb.path].append(wall if args.wall else e0.elapsed_time(e1) * 1e3 / args.steps)
     for p, ts in times.items():
-        print(f"{statistics.median(ts):8.3f} us median  {min(ts):8.3f} min  {max(ts):8.3f} max   {p}", flush=True)
+        print(f"{statistics.median(ts):8.3f} us median  {min(ts):8.3f} min  {max(ts):8.3f} max   host enqueue {statistics.median(host[p]):6.3f} us/step   {p}", flush=True)
+    if args.all:
+        for p, ts in times.items():
+            print("   reps:", " ".join(f"{t:.3f}" for t in ts), flush=True)
     for lb, h, _ in engines:
         lb.lib.gymrs_engine_destroy(h)
 
