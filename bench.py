@@ -297,8 +297,9 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
             if res.returncode != 0 or not dbs:
                 return None, f"rocprofv3 --pmc {ctr} failed (rc {res.returncode}): {res.stderr[-300:]}"
             c = sqlite3.connect(str(dbs[0]))
-            r = c.execute("select count(*), avg(value) from counters_collection where kernel_name like '%step_kernel%' "
-                          "and counter_name = ?", (ctr,)).fetchone()
+            # (the per-step kernel under either name: HIP's template instance, or the chain's copy in the stand-alone code object)
+            r = c.execute("select count(*), avg(value) from counters_collection where (kernel_name like '%step_kernel%' or "
+                          "kernel_name like ?) and counter_name = ?", (f"gymrs_aql_{env_name}_t%", ctr)).fetchone()
             out[ctr] = {"launches": r[0], "avg_kb": r[1]}
     fetch = 2.0 * out["FETCH_SIZE"]["avg_kb"] * 1024.0
     write = out["WRITE_SIZE"]["avg_kb"] * 1024.0
@@ -382,8 +383,7 @@ def run_rank(args, info, backend, make_collective=None):
     again = 1 if pinned else min(again, 4096)
     again = int(coll.max([again])[0])             # every rank steps the same number of times
     t0 = time.perf_counter()
-    for _ in range(again):
-        run_steps(args.steps)
+    run_steps(args.steps * again)  # ONE call, like a timed repetition (a chain per call: many short calls would be another workload)
     backend.sync()
     passes = choose_passes((time.perf_counter() - t0) / again)
     settle_ms = (time.perf_counter() - t_settle) * 1e3
@@ -394,7 +394,9 @@ def run_rank(args, info, backend, make_collective=None):
 
     # ---- the timed region ----
     reps = max(1, args.repetitions)
-    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps), passes, reps)
+    # One call per repetition: P passes of K steps = one gymrs_step_many(P * K) -- one chain of launches through the engine's own
+    # AQL dispatcher (gymrs_aql.h), or P * K HIP launches where that path is not available.
+    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps)
 
     # ---- read-out, after the clock: statistics all-reduce (the only collective of the path) ----
     backend.sync()
@@ -405,7 +407,16 @@ def run_rank(args, info, backend, make_collective=None):
     run.check_total_steps(total, steps_per_lane)
     # (kernels = max over ranks per repetition; every rank also reports its OWN event times)
     own_us = [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]]
-    per_rank = coll.gather_to_root({"rank": info.rank, "device": getattr(backend, "dev_index", None),
+    submission = None
+    if hasattr(eng, "env_json") and not args.rollout:
+        try:
+            ex = json.loads(eng.env_json(0))["gymrs"]
+            submission = ("AQL chains: the engine's own HSA queue, one chain per gymrs_step_many call, agent-scope acquire on every launch, "
+                          "release fence only at the end of the chain (gymrs_aql.h)") if ex.get("aql_launches", 0) > 0 else (
+                          "HIP launches (hipLaunchKernelGGL; AQL dispatcher: %s)" % ex.get("aql", "n/a"))
+        except Exception:  # noqa: BLE001 -- diagnostics only
+            submission = None
+    per_rank = coll.gather_to_root({"rank": info.rank, "device": getattr(backend, "dev_index", None), "submission": submission,
                                     "global_env_offset": run.offset,
                                     "launch_us": statistics.median(own_us), "launch_us_min": min(own_us), "launch_us_max": max(own_us),
                                     "cpu_affinity": getattr(args, "cpu_affinity", None), "numa_node": getattr(args, "numa_node", None)})
@@ -441,13 +452,15 @@ def run_rank(args, info, backend, make_collective=None):
                 "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
                 "hip_graph": bool(args.graph),
+                "submission": submission,
                 "parallelism": f"lane-sharded x{info.world}, no data-path collective; 1 all-reduce of 4 f64 per run, after the clock",
                 "stats_allreduce": allreduce_path,
             },
             "timing": {
                 "repetitions": reps,
                 "passes_per_repetition": passes,
-                "calibration_passes": 1 + again,  # untimed passes of K steps between the warm-up and the first repetition
+                # untimed steps between the warm-up and the first repetition: one call of K steps, then ONE call of (n - 1) * K steps
+                "calibration_passes": 1 + again,
                 "settle_ms": settle_ms,  # untimed stepping right before the first repetition (calibration passes included)
                 "steps_per_repetition": steps_timed,
                 "wall_ms_per_repetition": [w * 1e3 for w in walls],
@@ -473,8 +486,9 @@ def run_rank(args, info, backend, make_collective=None):
                 "bytes_per_env_step": bytes_per_step,
                 "bytes_per_launch": n * bytes_per_step,
                 "launch_us": launch_us,
-                "how": "HIP events on the engine stream around P*K back-to-back launches / (P*K), median of the repetitions "
-                       "(includes the inter-kernel gaps); rank 0's lanes",
+                "how": "HIP events on the engine's stream around ONE gymrs_step_many(P*K) call / (P*K), median of the repetitions: the "
+                       "back-to-back launches with their gaps, plus -- for an AQL chain -- its hand-over from and back to the stream; "
+                       "rank 0's lanes",
                 "kernel_source_sha16": sha,
             },
             "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},

@@ -33,6 +33,33 @@ extern "C" const char gymrs_aql_blob_end[];
 namespace gymrs {
 namespace {
 
+// The two HIP-launched ends of the hand-over (on the engine's stream).  Kernels, not stream memory operations: a
+// hipStreamWaitValue32 leaves the stream's hardware queue POLLING for as long as the chain runs, and a polling queue next to
+// the chain's queue cost every launch of the chain 0.25 us (profiles/r03_aql_engine_ab.log); one sleeping wavefront costs nothing.
+__global__ __launch_bounds__(64) void aql_hip_set_flag(uint32_t* flag, uint32_t seq)
+{
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Waits until the chain's last packet has stored `seq` (wrap-around safe).  Bounded by the 100 MHz real-time counter, not by a
+// poll count: kStreamWaitSeconds, far beyond any chain (aql_begin cuts chains off long before); a wait that runs out reports it.
+constexpr unsigned long long kStreamWaitTicks = 120ull * 100000000ull;
+__global__ __launch_bounds__(64) void aql_hip_wait_flag(const uint32_t* flag, uint32_t seq, uint32_t* err)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((int32_t)(v - seq) >= 0) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > kStreamWaitTicks) {
+            __hip_atomic_store(err, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+}
+
 constexpr uint32_t kQueuePackets = 4096;
 constexpr uint32_t kKernargSlots = 8 * kQueuePackets; // a slot is rewritten only after kQueuePackets later packets were CONSUMED
 constexpr uint32_t kFlushEvery = 64;
@@ -127,13 +154,12 @@ public:
     int device = 0;
     hsa_queue_t* q = nullptr;
     char* kernarg = nullptr;     // device memory, written by the CPU through the PCIe BAR
-    uint32_t* in_flag = nullptr; // device word the HIP stream writes (hipStreamWriteValue32), the chain's first packet waits for
-    uint32_t* out_flag = nullptr; // signal memory the chain's last packet writes, the HIP stream waits for (hipStreamWaitValue32)
+    uint32_t* in_flag = nullptr; // device word a one-wave kernel on the HIP stream writes, the chain's first packet waits for
+    uint32_t* out_flag = nullptr; // device word the chain's last packet writes, a one-wave kernel on the HIP stream waits for
     uint32_t* host_err = nullptr; // mapped host word: a wait that gave up
     uint32_t* host_err_dev = nullptr;
     uint32_t seq = 0;
     bool in_chain = false;
-    bool lazy_pending = false;
     std::atomic<int> queue_status{0};
     AqlKernel k_wait, k_set;
     // packets written but not yet published (headers still INVALID)
@@ -201,8 +227,13 @@ public:
         _mm_sfence();
 #endif
         if (last_kernarg) (void)*static_cast<volatile uint32_t*>(last_kernarg);
-        for (const Staged& s : staged) __atomic_store_n(reinterpret_cast<uint32_t*>(s.p), s.header_and_setup, __ATOMIC_RELEASE);
-        hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)staged.back().idx);
+        // One doorbell per packet (posted writes, cheap): rocprofiler's queue interception faults on a doorbell that publishes
+        // several packets at once (rocprofv3 --kernel-trace segfaulted inside its doorbell handler; with one packet per ring
+        // the same run is traced, profiles/r03_kernel_trace_*).
+        for (const Staged& s : staged) {
+            __atomic_store_n(reinterpret_cast<uint32_t*>(s.p), s.header_and_setup, __ATOMIC_RELEASE);
+            hsa_signal_store_screlease(q->doorbell_signal, (hsa_signal_value_t)s.idx);
+        }
         staged.clear();
     }
 };
@@ -218,12 +249,13 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe), "hsa_executable_create_alt");
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
-    static const char* names[] = {"gymrs_aql_cartpole_t512_nt", "gymrs_aql_cartpole_t512_pl", "gymrs_aql_cartpole_t256_nt", "gymrs_aql_cartpole_t256_pl",
-                                  "gymrs_aql_mountain_car_t256_nt", "gymrs_aql_mountain_car_t256_pl", "gymrs_aql_pendulum_t256_nt",
-                                  "gymrs_aql_pendulum_t256_pl", "gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
-    for (const char* nm : names) {
+    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
+    for (const char* stem : {"gymrs_aql_cartpole_t512", "gymrs_aql_cartpole_t256", "gymrs_aql_mountain_car_t256", "gymrs_aql_pendulum_t256"})
+        for (const char* hint : {"_nt", "_o", "_so", "_pl"}) names.push_back(std::string(stem) + hint);
+    for (const std::string& name : names) {
+        const char* nm = name.c_str();
         hsa_executable_symbol_t sym;
-        HSA_OK(hsa_executable_get_symbol_by_name(c->exe, (std::string(nm) + ".kd").c_str(), &c->gpu, &sym), nm);
+        HSA_OK(hsa_executable_get_symbol_by_name(c->exe, (name + ".kd").c_str(), &c->gpu, &sym), nm);
         AqlKernel k;
         HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object), nm);
         HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_bytes), nm);
@@ -330,12 +362,6 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
 
 bool init_device(DeviceCtx* c, int device, std::string* why)
 {
-    int can_wait = 0;
-    HIP_OK(hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device), "hipDeviceGetAttribute");
-    if (!can_wait) {
-        *why = "the device has no stream memory operations (hipStreamWaitValue32)";
-        return false;
-    }
     char bus[64] = {0};
     HIP_OK(hipDeviceGetPCIBusId(bus, sizeof(bus), device), "hipDeviceGetPCIBusId");
     unsigned dom = 0, b = 0, d = 0, f = 0;
@@ -397,11 +423,11 @@ AqlChain* aql_create(int hip_device, std::string* why)
         ch->in_flag = static_cast<uint32_t*>(p);
         if (!ok) *why = "hipMalloc (hand-over flag) failed";
     }
-    if (ok) { // what hipStreamWaitValue32 can wait on: signal memory
+    if (ok) {
         void* p = nullptr;
-        ok = hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess;
+        ok = hipMalloc(&p, 64) == hipSuccess && hipMemset(p, 0, 64) == hipSuccess;
         ch->out_flag = static_cast<uint32_t*>(p);
-        if (!ok) *why = "hipExtMallocWithFlags(hipMallocSignalMemory) failed";
+        if (!ok) *why = "hipMalloc (hand-over flag) failed";
     }
     if (ok) {
         void* p = nullptr;
@@ -417,8 +443,6 @@ AqlChain* aql_create(int hip_device, std::string* why)
     if (ok) { // the hand-over itself, once, on a stream of its own: begin -> end must let the stream through
         hipStream_t probe = nullptr;
         ok = hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) == hipSuccess;
-        if (ok) ok = hipStreamWriteValue32(probe, ch->out_flag, 0, 0) == hipSuccess && hipStreamSynchronize(probe) == hipSuccess;
-        if (!ok) *why = "initialising the hand-over flags through the stream failed";
         if (ok) ok = aql_begin(ch, probe, why) && aql_end(ch, probe, why);
         if (ok) {
             const auto t0 = std::chrono::steady_clock::now();
@@ -465,7 +489,8 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
     }
     c->seq += 1;
     // behind everything enqueued on the engine's stream so far ...
-    HIP_OK(hipStreamWriteValue32(stream, c->in_flag, c->seq, 0), "hipStreamWriteValue32");
+    hipLaunchKernelGGL(aql_hip_set_flag, dim3(1), dim3(64), 0, stream, c->in_flag, c->seq);
+    HIP_OK(hipGetLastError(), "hand-over into the chain");
     // ... and the chain's first packet waits for it
     struct {
         const uint32_t* flag;
@@ -506,22 +531,9 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
     if (!c->stage(c->k_set, 64, 64, &scratch, sizeof(scratch), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     if (!c->stage(c->k_set, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     c->publish();
-    if (std::getenv("GYMRS_AQL_LAZY_WAIT")) { // EXPERIMENT: no wait on the stream; aql_host_wait() polls from the host
-        c->lazy_pending = true;
-        return true;
-    }
-    HIP_OK(hipStreamWaitValue32(stream, c->out_flag, c->seq, hipStreamWaitValueGte, 0xffffffffu), "hipStreamWaitValue32");
+    hipLaunchKernelGGL(aql_hip_wait_flag, dim3(1), dim3(64), 0, stream, c->out_flag, c->seq, c->host_err_dev);
+    HIP_OK(hipGetLastError(), "hand-over back to the stream");
     return true;
-}
-
-void aql_host_wait(AqlChain* c)
-{
-    if (!c || !c->lazy_pending) return;
-    const auto t0 = std::chrono::steady_clock::now();
-    while ((int32_t)(__atomic_load_n(c->out_flag, __ATOMIC_ACQUIRE) - c->seq) < 0) {
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) break;
-    }
-    c->lazy_pending = false;
 }
 
 uint32_t aql_take_error(AqlChain* c)

@@ -218,10 +218,15 @@ static uint64_t os_entropy()
 //     the cache the churn.
 // In between (2^21 .. 2^23 CartPole lanes) the Infinity Cache serves part of the next step's reads and plain accesses
 // win (2^22 lanes: 25.6 vs 30.1 us).
-static uint32_t launch_flags_of(const gymrs_engine* e)
+static uint64_t bytes_per_step(const gymrs_engine* e)
 {
     const uint64_t bytes_per_lane = (uint64_t)e->state_dim * 8 + 10 + (e->kind == GYMRS_PENDULUM ? 8 : 0);
-    const uint64_t per_step = e->n * bytes_per_lane;
+    return e->n * bytes_per_lane;
+}
+
+static uint32_t launch_flags_of(const gymrs_engine* e)
+{
+    const uint64_t per_step = bytes_per_step(e);
     const bool streaming = per_step <= (48ull << 20) || per_step >= (340ull << 20);
     const bool nt = e->nt_mode == 1 || (e->nt_mode == 0 && streaming);
     return e->flags | (nt ? kFlagNonTemporal : 0u);
@@ -1215,24 +1220,35 @@ static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stri
 // through HIP launches.
 constexpr uint32_t kAqlMinChain = 8;
 
-static const char* aql_kernel_name(const gymrs_engine* e, uint32_t flags, int threads)
+static std::string aql_kernel_name(const gymrs_engine* e, uint32_t flags, int threads)
 {
-    const bool nt = (flags & kFlagNonTemporal) != 0;
     constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
     const uint32_t f = flags & (A | S | T);
+    const char* stem = nullptr;
     switch (e->kind) {
-    case GYMRS_CARTPOLE:
-        if (f != (A | S)) return nullptr;
-        return threads == kCartPoleThreads ? (nt ? "gymrs_aql_cartpole_t512_nt" : "gymrs_aql_cartpole_t512_pl")
-                                           : (nt ? "gymrs_aql_cartpole_t256_nt" : "gymrs_aql_cartpole_t256_pl");
-    case GYMRS_MOUNTAIN_CAR:
-        if (f != (A | S)) return nullptr;
-        return nt ? "gymrs_aql_mountain_car_t256_nt" : "gymrs_aql_mountain_car_t256_pl";
-    case GYMRS_PENDULUM:
-        if (f != (A | S | T)) return nullptr;
-        return nt ? "gymrs_aql_pendulum_t256_nt" : "gymrs_aql_pendulum_t256_pl";
+    case GYMRS_CARTPOLE: stem = f == (A | S) ? (threads == kCartPoleThreads ? "gymrs_aql_cartpole_t512" : "gymrs_aql_cartpole_t256") : nullptr; break;
+    case GYMRS_MOUNTAIN_CAR: stem = f == (A | S) ? "gymrs_aql_mountain_car_t256" : nullptr; break;
+    case GYMRS_PENDULUM: stem = f == (A | S | T) ? "gymrs_aql_pendulum_t256" : nullptr; break;
     }
-    return nullptr;
+    if (!stem) return std::string();
+    const uint32_t h = flags & kFlagHintMask;
+    const char* hint = (h & kFlagNonTemporal) ? "_nt" : (h == (kFlagNtOut | kFlagNtStateLoads) ? "_so" : (h == kFlagNtOut ? "_o" : (h == 0 ? "_pl" : nullptr)));
+    return hint ? std::string(stem) + hint : std::string();
+}
+
+// Memory hints of a chain's launches (profiles/r03_chain_hints.log; us per step, chain with plain / out / state-loads+out hints):
+// a chain lives off the lines the previous launch left in the L2s -- no write-back between its links -- so the state STORES are
+// never streamed.  What nobody reads again (reward, done, truncated, cos / sin) is: CartPole 2^20 lanes 5.44 -> 5.02, 2^21
+// 13.5 -> 12.3, Pendulum 2^20 4.76 -> 4.10, 2^21 13.4 -> 11.6.  While one step's arrays are small next to the caches the state
+// loads are streamed too (CartPole 2^20: 4.91; at 2^21 it costs 1.3 us).  Far beyond the caches everything streams, as for HIP
+// launches.  (Streaming the ACTION loads alone costs a 2^20-lane CartPole chain a full microsecond.)
+static uint32_t chain_hint_bits(const gymrs_engine* e)
+{
+    if (e->nt_mode == 1) return kFlagNonTemporal;
+    if (e->nt_mode == 2) return 0u;
+    const uint64_t per_step = bytes_per_step(e);
+    if (per_step >= (340ull << 20)) return kFlagNonTemporal;
+    return per_step <= (48ull << 20) ? (kFlagNtOut | kFlagNtStateLoads) : kFlagNtOut;
 }
 
 static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
@@ -1240,7 +1256,7 @@ static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
     if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host || e->limit_elidable) return false;
     if (const char* v = std::getenv("GYMRS_AQL")) // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
         if (v[0] == '0') return false;
-    if (!aql_kernel_name(e, e->flags, kBlock)) return false;
+    if (aql_kernel_name(e, e->flags, kBlock).empty()) return false;
     if (!e->own_stream) { // a caller-provided stream may be under a capture: a chain cannot be captured
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(e->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
@@ -1289,7 +1305,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     }
     *taken = true;
     const int threads = step_threads_of(e->kind, e->n, e->vec);
-    const char* last_name = nullptr;
+    uint32_t last_hints = ~0u;
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
         const std::string msg = g_last_error;
@@ -1301,12 +1317,13 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     for (uint32_t t = first; t < n_steps; ++t) {
         uint32_t flags = 0;
         if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
+        flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
-        const char* name = aql_kernel_name(e, flags, threads);
-        if (name != last_name) {
-            if (!name || !aql_kernel(e->aql, name, &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));
-            last_name = name;
+        if ((flags & kFlagHintMask) != last_hints) {
+            const std::string name = aql_kernel_name(e, flags, threads);
+            if (name.empty() || !aql_kernel(e->aql, name.c_str(), &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));
+            last_hints = flags & kFlagHintMask;
         }
         bool ok = false;
         switch (e->kind) {
@@ -1400,13 +1417,14 @@ gymrs_status gymrs_sync(gymrs_engine* e)
     if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    aql_host_wait(e->aql);
     std::atomic_thread_fence(std::memory_order_acquire);
     if (e->aql) {
-        if (const uint32_t bad = aql_take_error(e->aql))
-            return fail(GYMRS_EHIP, (bad & 2u) ? "the AQL queue reported an error"
-                                               : "a gymrs_step_many chain ran without waiting for the engine's stream: the stream did not reach "
-                                                 "the hand-over point within ~2 s (is it blocked on work that was never submitted?)");
+        if (const uint32_t bad = aql_take_error(e->aql)) {
+            if (bad & 2u) return fail(GYMRS_EHIP, "the AQL queue reported an error");
+            if (bad & 4u) return fail(GYMRS_EHIP, "the engine's stream gave up waiting for a gymrs_step_many chain (120 s)");
+            return fail(GYMRS_EHIP, "a gymrs_step_many chain ran without waiting for the engine's stream: the stream did not reach the "
+                                    "hand-over point within ~10 s (is it blocked on work that was never submitted?)");
+        }
     }
     if (*e->err_seen == 0) return GYMRS_OK; // no kernel saw an invalid action: nothing to fetch
     uint32_t err[2] = {0, 0};

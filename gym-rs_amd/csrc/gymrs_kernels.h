@@ -9,6 +9,12 @@ namespace gymrs {
 
 constexpr int kBlock = 256; // work-items per workgroup of the small kernels (reset, fill, statistics) and of the rollout kernel
 constexpr uint32_t kFlagNonTemporal = 0x100u; // internal launch flag (not an engine flag): non-temporal loads/stores
+// Hints per class of access, for the launches of a chain (gymrs_aql.h): only the stores nobody reads again (reward, done,
+// truncated, Pendulum's cos / sin), and additionally the state LOADS (the state stores stay plain: the next launch reads them
+// out of the L2).  Measured per size in profiles/r03_chain_hints.log; the engine picks (chain_hint_bits).
+constexpr uint32_t kFlagNtOut = 0x200u;
+constexpr uint32_t kFlagNtStateLoads = 0x400u;
+constexpr uint32_t kFlagHintMask = kFlagNonTemporal | kFlagNtOut | kFlagNtStateLoads;
 // Rows of the reset log.  Measured at 2^20 CartPole lanes (128 KiB per row, no folding): a ring of <= 8 rows stays where a
 // write is cheap (6.10 us per launch; 8 steps x 40 MB is about what passes through the 256 MB Infinity Cache before a line
 // is evicted), 16 rows 6.22, >= 32 rows 6.40 (touching the next row one step ahead with a scalar load made it worse:

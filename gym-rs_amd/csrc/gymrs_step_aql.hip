@@ -18,30 +18,34 @@ using namespace gymrs;
         step_kernel_body<ENV_, 4, FLAGS_, THREADS_>(s0, s1, s2, s3, action, n_fast, rest, c);                                             \
     }
 
-constexpr uint32_t kAS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, kAST = kAS | GYMRS_TIME_LIMIT, kNT = kFlagNonTemporal;
-GYMRS_AQL_STEP(gymrs_aql_cartpole_t512_nt, CartPoleT, kAS | kNT, 512)
-GYMRS_AQL_STEP(gymrs_aql_cartpole_t512_pl, CartPoleT, kAS, 512)
-GYMRS_AQL_STEP(gymrs_aql_cartpole_t256_nt, CartPoleT, kAS | kNT, 256)
-GYMRS_AQL_STEP(gymrs_aql_cartpole_t256_pl, CartPoleT, kAS, 256)
-GYMRS_AQL_STEP(gymrs_aql_mountain_car_t256_nt, MountainCarT, kAS | kNT, 256)
-GYMRS_AQL_STEP(gymrs_aql_mountain_car_t256_pl, MountainCarT, kAS, 256)
-GYMRS_AQL_STEP(gymrs_aql_pendulum_t256_nt, PendulumT, kAST | kNT, 256)
-GYMRS_AQL_STEP(gymrs_aql_pendulum_t256_pl, PendulumT, kAST, 256)
+constexpr uint32_t kAS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, kAST = kAS | GYMRS_TIME_LIMIT;
+// hint variants: _nt every access, _o only the stores nobody reads again, _so those plus the state loads, _pl none
+#define GYMRS_AQL_STEP_HINTS(PREFIX_, ENV_, FLAGS_, THREADS_)                     \
+    GYMRS_AQL_STEP(PREFIX_##_nt, ENV_, (FLAGS_) | kFlagNonTemporal, THREADS_)     \
+    GYMRS_AQL_STEP(PREFIX_##_o, ENV_, (FLAGS_) | kFlagNtOut, THREADS_)            \
+    GYMRS_AQL_STEP(PREFIX_##_so, ENV_, (FLAGS_) | kFlagNtOut | kFlagNtStateLoads, THREADS_) \
+    GYMRS_AQL_STEP(PREFIX_##_pl, ENV_, (FLAGS_), THREADS_)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t512, CartPoleT, kAS, 512)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t256, CartPoleT, kAS, 256)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_mountain_car_t256, MountainCarT, kAS, 256)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_pendulum_t256, PendulumT, kAST, 256)
 
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put
 // behind everything that was enqueued there before (flag >= seq, wrap-around safe).  Bounded: a stream that never gets
-// there (blocked on work nobody submits) must not hang the queue -- the wait gives up after ~2 s of polling, sets err[0] and
+// there (blocked on work nobody submits) must not hang the queue -- the wait gives up after ~10 s, sets err[0] and
 // lets the chain run (gymrs_sync reports it).
 extern "C" __global__ __launch_bounds__(64) void gymrs_aql_wait_flag(const uint32_t* flag, uint32_t seq, uint32_t* err)
 {
     if (threadIdx.x != 0) return;
-    for (uint32_t spins = 0; spins < (1u << 21); ++spins) { // ~1 us per poll
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
+    for (;;) {
         const uint32_t v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((int32_t)(v - seq) >= 0) {
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             return;
         }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 10ull * 100000000ull) break;
         __builtin_amdgcn_s_sleep(32);
     }
     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -111,7 +111,11 @@ struct CartPoleT {
     static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
     static constexpr float kReward = 1.0f;
     static constexpr bool kElideConstReward = false; // measured: +1 % here (VALU-bound; the flag load costs more than 4 B per lane of stores)
+#ifdef GYMRS_EXP_NO_RESET_LOG // (developer builds: ablation)
+    static constexpr bool kUseResetLog = false;
+#else
     static constexpr bool kUseResetLog = true;       // measured: 6.67 -> 6.44 us per 2^20-lane step (1 lane in 22 re-arms per step)
+#endif
     static constexpr bool kHasBeyond = true;
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
@@ -223,7 +227,7 @@ struct TileRegs {
     static constexpr bool NT_SL = (GYMRS_EXP_HINTS & 1) != 0, NT_SS = (GYMRS_EXP_HINTS & 2) != 0, NT_A = (GYMRS_EXP_HINTS & 4) != 0,
                           NT_O = (GYMRS_EXP_HINTS & 8) != 0;
 #else
-    static constexpr bool NT_SL = NT, NT_SS = NT, NT_A = NT, NT_O = NT;
+    static constexpr bool NT_SL = NT || (FLAGS & kFlagNtStateLoads) != 0, NT_SS = NT, NT_A = NT, NT_O = NT || (FLAGS & kFlagNtOut) != 0;
 #endif
     // Episode bookkeeping of the per-step kernel goes through the reset log (StepArgs::reset_log) when nothing in the
     // step needs ep_start itself: statistics on, no time limit, constant reward (return = +-length).

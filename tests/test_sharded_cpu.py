@@ -224,11 +224,11 @@ def check_against_one_unsharded_twin(tmp_path, twin, out, world, n=3001, steps=7
             full.step(ring[t % 4])
 
     run(warmup)
-    for _ in range(out["timing"]["calibration_passes"]):  # bench's untimed calibration passes
-        run(steps)
+    run(steps)  # bench's untimed calibration: one call of K steps, then ONE call with the rest
+    run(steps * (out["timing"]["calibration_passes"] - 1))
     full.stats_clear()
-    for _ in range(reps * passes):
-        run(steps)
+    for _ in range(reps):  # a repetition is ONE step_many call of passes * steps steps (the ring index runs through)
+        run(steps * passes)
     want = full.stats()
     got = out["episodes"]
     assert (got["sum_return"], got["sum_length"], got["n_episodes"]) == (want[0], want[1], want[2])
