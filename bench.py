@@ -286,7 +286,7 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = Path(tmp) / ctr
             cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
-                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--repetitions", "2"]
+                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
             if args.n_envs:
                 cmd += ["--n-envs", str(args.n_envs)]
             if args.vec:
@@ -372,6 +372,8 @@ def run_rank(args, info, backend, make_collective=None):
     if coll.active:
         run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
     backend.sync()
+    run_steps(args.steps)  # priming call: whatever the first full call sets up (the engine's AQL chain object, its self-check) is not stepping
+    backend.sync()
     t_settle = time.perf_counter()
     t0 = time.perf_counter()
     run_steps(args.steps)  # first calibration pass: clocks may still be ramping up after a short warm-up
@@ -385,7 +387,16 @@ def run_rank(args, info, backend, make_collective=None):
     t0 = time.perf_counter()
     run_steps(args.steps * again)  # ONE call, like a timed repetition (a chain per call: many short calls would be another workload)
     backend.sync()
-    passes = choose_passes((time.perf_counter() - t0) / again)
+    per_pass = (time.perf_counter() - t0) / again
+    calibration_calls = [args.steps, args.steps, args.steps * again]
+    # (the estimate came from a SHORT call, which overstates the time per step: top the settle phase up if it fell short)
+    short = 0.0 if pinned else SETTLE_SECONDS - (time.perf_counter() - t_settle)
+    more = int(coll.max([math.ceil(short / max(per_pass, 1e-9)) if short > 0 else 0])[0])
+    if more > 0:
+        run_steps(args.steps * more)
+        backend.sync()
+        calibration_calls.append(args.steps * more)
+    passes = choose_passes(per_pass)
     settle_ms = (time.perf_counter() - t_settle) * 1e3
     if pinned:
         passes = max(1, int(pinned))
@@ -396,14 +407,18 @@ def run_rank(args, info, backend, make_collective=None):
     reps = max(1, args.repetitions)
     # One call per repetition: P passes of K steps = one gymrs_step_many(P * K) -- one chain of launches through the engine's own
     # AQL dispatcher (gymrs_aql.h), or P * K HIP launches where that path is not available.
-    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps)
+    # One more repetition up front, reported but not counted: stats_clear's kernels have just swept the episode bookkeeping
+    # through the caches, and the first call after them runs ~5 % slower than the rest.
+    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps + 1)
+    lead_in_us = kernels[0] * 1e3 / (args.steps * passes)
+    walls, kernels = walls[1:], kernels[1:]
 
     # ---- read-out, after the clock: statistics all-reduce (the only collective of the path) ----
     backend.sync()
     t0 = time.perf_counter()
     total = run.allreduce_stats()
     stats_readout_us = (time.perf_counter() - t0) * 1e6
-    steps_per_lane = args.steps * passes * reps
+    steps_per_lane = args.steps * passes * (reps + 1)  # (the lead-in repetition steps too)
     run.check_total_steps(total, steps_per_lane)
     # (kernels = max over ranks per repetition; every rank also reports its OWN event times)
     own_us = [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]]
@@ -459,8 +474,10 @@ def run_rank(args, info, backend, make_collective=None):
             "timing": {
                 "repetitions": reps,
                 "passes_per_repetition": passes,
-                # untimed steps between the warm-up and the first repetition: one call of K steps, then ONE call of (n - 1) * K steps
-                "calibration_passes": 1 + again,
+                # untimed calls between the warm-up and the first repetition, in steps per call (priming, rate, settle)
+                "calibration_passes": sum(calibration_calls) // args.steps,
+                "calibration_calls": calibration_calls,
+                "lead_in_repetition_us_per_step": lead_in_us,  # the uncounted repetition right after stats_clear
                 "settle_ms": settle_ms,  # untimed stepping right before the first repetition (calibration passes included)
                 "steps_per_repetition": steps_timed,
                 "wall_ms_per_repetition": [w * 1e3 for w in walls],
@@ -514,6 +531,11 @@ def run_rank(args, info, backend, make_collective=None):
             roof["traffic"] = traffic
             if note:
                 roof["traffic_note"] = note
+            if traffic and submission and submission.startswith("AQL"):
+                roof["traffic_measured_on"] = ("the same kernel launched through HIP with every access hinted: rocprofv3's counter collection "
+                                               "serialises kernels across queues, which a chain's hand-over cannot live with (the dispatcher's "
+                                               "self-check then sends the launches through HIP); the chain's own variant streams only the state "
+                                               "loads and the stores nobody reads again, and leaves its state stores in the L2s")
             if traffic:
                 # what is MOVED next to what is COUNTED: MountainCar elides its constant reward store, Pendulum's theta_dot
                 # observation column aliases the state column

@@ -58,5 +58,7 @@ bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* err);
 // != 0 once a chain's first packet gave up waiting for the stream (checked by gymrs_sync); cleared by the call
 uint32_t aql_take_error(AqlChain* c);
+// the chains of this object use the synchronous hand-over (the host waits on both sides): see aql_create
+bool aql_is_synchronous(const AqlChain* c);
 
 } // namespace gymrs

@@ -95,6 +95,7 @@ struct DeviceCtx {
     hsa_amd_memory_pool_t gpu_pool{};
     hsa_executable_t exe{};
     std::map<std::string, AqlKernel> kernels;
+    int concurrent_handover = -1; // -1 not tried yet, 1 works, 0 kernels of two queues do not run side by side here (see aql_create)
 };
 
 constexpr int kMaxDevices = 64;
@@ -160,6 +161,12 @@ public:
     uint32_t* host_err_dev = nullptr;
     uint32_t seq = 0;
     bool in_chain = false;
+    // Synchronous hand-over: the host waits for the stream before a chain and for the chain after it.  Used where the two
+    // one-wave kernels of the asynchronous hand-over cannot be in flight together -- under rocprofv3 --pmc, whose counter
+    // collection serialises kernels across queues (the asynchronous form would wait out its bound there).
+    bool sync_mode = false;
+    hsa_signal_t done{};
+    unsigned long long wait_ticks = 10ull * 100000000ull; // bound of the chain's first packet (100 MHz ticks)
     std::atomic<int> queue_status{0};
     AqlKernel k_wait, k_set;
     // packets written but not yet published (headers still INVALID)
@@ -440,22 +447,39 @@ AqlChain* aql_create(int hip_device, std::string* why)
         if (!ok) *why = "hipHostMalloc (error word) failed";
     }
     if (ok) ok = hipDeviceSynchronize() == hipSuccess;
-    if (ok) { // the hand-over itself, once, on a stream of its own: begin -> end must let the stream through
+    if (ok) ok = hsa_signal_create(1, 0, nullptr, &ch->done) == HSA_STATUS_SUCCESS;
+    if (ok && c->concurrent_handover == 0) ch->sync_mode = true;
+    if (ok && c->concurrent_handover < 0) {
+        // The asynchronous hand-over itself, once per device, on a stream of its own: begin -> end must let the stream through.
+        // It needs a kernel of the stream and a kernel of the chain in flight TOGETHER; where they are not (rocprofv3 --pmc
+        // serialises kernels across queues) the chain's first packet runs out its -- here: short -- bound, and the chains of
+        // this device use the synchronous hand-over instead.
         hipStream_t probe = nullptr;
         ok = hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) == hipSuccess;
+        ch->wait_ticks = 100000000ull; // 1 s
         if (ok) ok = aql_begin(ch, probe, why) && aql_end(ch, probe, why);
         if (ok) {
             const auto t0 = std::chrono::steady_clock::now();
             hipError_t q = hipErrorNotReady;
-            while ((q = hipStreamQuery(probe)) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5)) {
+            while ((q = hipStreamQuery(probe)) == hipErrorNotReady && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(8)) {
             }
-            ok = q == hipSuccess && aql_take_error(ch) == 0;
-            if (!ok) *why = "hand-over self-check: the stream did not come through an empty chain within 5 s";
+            const uint32_t gave_up = aql_take_error(ch);
+            if (q != hipSuccess) {
+                ok = false;
+                *why = "hand-over self-check: the stream did not come through an empty chain within 8 s";
+                std::lock_guard<std::mutex> lock(g_mu);
+                c->ok = false; // (the stuck stream and this chain's queue are left alone; no further attempts on this device)
+                c->why = *why;
+            } else {
+                std::lock_guard<std::mutex> lock(g_mu);
+                c->concurrent_handover = gave_up ? 0 : 1;
+                ch->sync_mode = gave_up != 0;
+            }
         }
-        if (ok && probe) (void)hipStreamDestroy(probe); // (a stream that is stuck behind a wait is left alone)
+        ch->wait_ticks = 10ull * 100000000ull;
+        if (ok && probe) (void)hipStreamDestroy(probe);
     }
     if (!ok) {
-        // (a chain whose hand-over got stuck keeps its queue and flags: tearing them down under a pending wait could fault)
         if (why->find("hand-over self-check") == std::string::npos) aql_destroy(ch);
         return nullptr;
     }
@@ -466,6 +490,7 @@ void aql_destroy(AqlChain* c)
 {
     if (!c) return;
     if (c->q) hsa_queue_destroy(c->q);
+    if (c->done.handle) hsa_signal_destroy(c->done);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
     if (c->in_flag) (void)hipFree(c->in_flag);
     if (c->out_flag) (void)hipFree(c->out_flag);
@@ -488,6 +513,11 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
         return false;
     }
     c->seq += 1;
+    if (c->sync_mode) {
+        HIP_OK(hipStreamSynchronize(stream), "hipStreamSynchronize (synchronous hand-over)");
+        c->in_chain = true;
+        return true;
+    }
     // behind everything enqueued on the engine's stream so far ...
     hipLaunchKernelGGL(aql_hip_set_flag, dim3(1), dim3(64), 0, stream, c->in_flag, c->seq);
     HIP_OK(hipGetLastError(), "hand-over into the chain");
@@ -497,7 +527,8 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
         uint32_t seq;
         uint32_t pad;
         uint32_t* err;
-    } args{c->in_flag, c->seq, 0, c->host_err_dev};
+        unsigned long long max_ticks;
+    } args{c->in_flag, c->seq, 0, c->host_err_dev, c->wait_ticks};
     if (!c->stage(c->k_wait, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_SYSTEM, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0}, why)) return false;
     c->in_chain = true;
     return true;
@@ -528,6 +559,16 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
         uint32_t* flag;
         uint32_t seq;
     } scratch{c->in_flag + 8, c->seq}, args{c->out_flag, c->seq};
+    if (c->sync_mode) { // the host itself waits for the packet whose release writes the chain back
+        hsa_signal_store_relaxed(c->done, 1);
+        if (!c->stage(c->k_set, 64, 64, &scratch, sizeof(scratch), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, c->done, why)) return false;
+        c->publish();
+        if (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, 1, 120ull * 1000 * 1000 * 1000, HSA_WAIT_STATE_BLOCKED) >= 1) {
+            *why = "a chain did not finish within 120 s (synchronous hand-over)";
+            return false;
+        }
+        return true;
+    }
     if (!c->stage(c->k_set, 64, 64, &scratch, sizeof(scratch), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     if (!c->stage(c->k_set, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     c->publish();
@@ -535,6 +576,8 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
     HIP_OK(hipGetLastError(), "hand-over back to the stream");
     return true;
 }
+
+bool aql_is_synchronous(const AqlChain* c) { return c && c->sync_mode; }
 
 uint32_t aql_take_error(AqlChain* c)
 {

@@ -1931,7 +1931,8 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
     g.uint("max_episode_steps", max_episode_steps);
     // chains of per-step launches that went through the engine's own AQL dispatcher (gymrs_aql.h), and why not if none can
     g.uint("aql_chains", e->aql_chains).uint("aql_launches", e->aql_launches);
-    g.str("aql", e->aql ? "on" : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
+    g.str("aql", e->aql ? (aql_is_synchronous(e->aql) ? "on (synchronous hand-over: kernels of two queues do not run side by side here)" : "on")
+                        : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
     if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
         g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
         g.uint("time_limit_waits", e->age_waits).uint("time_limit_wait_us", e->age_wait_ns / 1000);

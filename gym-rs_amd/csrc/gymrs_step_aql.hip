@@ -33,9 +33,9 @@ GYMRS_AQL_STEP_HINTS(gymrs_aql_pendulum_t256, PendulumT, kAST, 256)
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put
 // behind everything that was enqueued there before (flag >= seq, wrap-around safe).  Bounded: a stream that never gets
-// there (blocked on work nobody submits) must not hang the queue -- the wait gives up after ~10 s, sets err[0] and
+// there (blocked on work nobody submits) must not hang the queue -- the wait gives up after max_ticks (10 s), sets err[0] and
 // lets the chain run (gymrs_sync reports it).
-extern "C" __global__ __launch_bounds__(64) void gymrs_aql_wait_flag(const uint32_t* flag, uint32_t seq, uint32_t* err)
+extern "C" __global__ __launch_bounds__(64) void gymrs_aql_wait_flag(const uint32_t* flag, uint32_t seq, uint32_t* err, unsigned long long max_ticks)
 {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(); // 100 MHz
@@ -45,7 +45,7 @@ extern "C" __global__ __launch_bounds__(64) void gymrs_aql_wait_flag(const uint3
             __atomic_thread_fence(__ATOMIC_ACQUIRE);
             return;
         }
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 10ull * 100000000ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
         __builtin_amdgcn_s_sleep(32);
     }
     __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

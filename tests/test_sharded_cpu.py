@@ -224,15 +224,16 @@ def check_against_one_unsharded_twin(tmp_path, twin, out, world, n=3001, steps=7
             full.step(ring[t % 4])
 
     run(warmup)
-    run(steps)  # bench's untimed calibration: one call of K steps, then ONE call with the rest
-    run(steps * (out["timing"]["calibration_passes"] - 1))
+    assert sum(out["timing"]["calibration_calls"]) == steps * out["timing"]["calibration_passes"]
+    for k in out["timing"]["calibration_calls"]:  # bench's untimed calibration calls (the ring index restarts with every call)
+        run(k)
     full.stats_clear()
-    for _ in range(reps):  # a repetition is ONE step_many call of passes * steps steps (the ring index runs through)
+    for _ in range(reps + 1):  # a repetition is ONE step_many call of passes * steps steps; one uncounted lead-in repetition
         run(steps * passes)
     want = full.stats()
     got = out["episodes"]
     assert (got["sum_return"], got["sum_length"], got["n_episodes"]) == (want[0], want[1], want[2])
-    assert want[3] == world * n * steps * passes * reps
+    assert want[3] == world * n * steps * passes * (reps + 1)
     # shard invariance of the state itself: rank r's lanes are lanes [r*n, (r+1)*n) of the unsharded batch, bit for bit
     cat = np.concatenate([np.load(tmp_path / f"state{r}.npy") for r in range(world)], axis=1)
     assert np.array_equal(cat.view(np.uint32), full.get_state().view(np.uint32))

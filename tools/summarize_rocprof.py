@@ -21,14 +21,14 @@ def kernel_summary(db, out):
              f"{'calls':>7} {'total_ns':>12} {'avg_ns':>10} {'min_ns':>8} {'max_ns':>8} {'pct':>6}  kernel"]
     for name, n, tot, avg, mn, mx in rows:
         lines.append(f"{n:>7} {tot:>12} {avg:>10.1f} {mn:>8} {mx:>8} {100.0 * tot / total:>6.2f}  {name}")
-    ks = c.execute("select start, end from kernels where (name like '%step_kernel%' or name like 'gymrs_aql_%_t%') order by start").fetchall()
+    ks = c.execute("select start, end from kernels where (name like '%step_kernel%' or name like 'gymrs_aql_cartpole%' or name like 'gymrs_aql_mountain%' or name like 'gymrs_aql_pendulum%') order by start").fetchall()
     if len(ks) > 20:
         skip = len(ks) // 10
         durs = [e - s for s, e in ks[skip:]]
         period = (ks[-1][0] - ks[skip][0]) / (len(ks) - 1 - skip)
         lines += ["", f"step_kernel: n={len(ks)} median duration {statistics.median(durs):.0f} ns, mean {statistics.mean(durs):.0f} ns, "
                       f"mean start-to-start period {period:.0f} ns (after skipping the first {skip})"]
-        r = c.execute("select grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels where (name like '%step_kernel%' or name like 'gymrs_aql_%_t%') limit 1").fetchone()
+        r = c.execute("select grid_x, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels where (name like '%step_kernel%' or name like 'gymrs_aql_cartpole%' or name like 'gymrs_aql_mountain%' or name like 'gymrs_aql_pendulum%') limit 1").fetchone()
         lines.append(f"step_kernel dispatch: grid_x={r[0]} workgroup_x={r[1]} lds={r[2]} vgpr={r[3]} sgpr={r[4]} scratch={r[5]}")
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
@@ -37,7 +37,7 @@ def kernel_summary(db, out):
 def counter_avg(db, counter):
     c = sqlite3.connect(db)
     r = c.execute("select count(*), avg(value), min(value), max(value) from counters_collection where (kernel_name like "
-                  "'%step_kernel%' or kernel_name like 'gymrs_aql_%_t%') and counter_name = ?", (counter,)).fetchone()
+                  "'%step_kernel%' or kernel_name like 'gymrs_aql_cartpole%' or name like 'gymrs_aql_mountain%' or name like 'gymrs_aql_pendulum%') and counter_name = ?", (counter,)).fetchone()
     return {"launches": r[0], "avg": r[1], "min": r[2], "max": r[3]}
 
 
