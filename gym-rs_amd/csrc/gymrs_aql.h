@@ -60,5 +60,8 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* err);
 uint32_t aql_take_error(AqlChain* c);
 // the chains of this object use the synchronous hand-over (the host waits on both sides): see aql_create
 bool aql_is_synchronous(const AqlChain* c);
+// Decides, for this stream, between the asynchronous hand-over and the synchronous one (AqlChain::calibrated_for).  Cheap after
+// the first call per stream.  Returns a description when it decided anew (valid until the next call), NULL otherwise.
+const char* aql_calibrate(AqlChain* c, hipStream_t stream);
 
 } // namespace gymrs

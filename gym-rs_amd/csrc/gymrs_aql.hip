@@ -165,6 +165,13 @@ public:
     // one-wave kernels of the asynchronous hand-over cannot be in flight together -- under rocprofv3 --pmc, whose counter
     // collection serialises kernels across queues (the asynchronous form would wait out its bound there).
     bool sync_mode = false;
+    // Decided per stream by aql_calibrate(): a kernel in flight on the stream's hardware queue next to the chain's queue -- the
+    // asynchronous hand-over needs one -- is free on some placements of the two queues and costs the chain a factor of 3-6 on
+    // others (the second and third engine of a process: profiles/r03_two_engines.log); a hipStreamWaitValue32 instead of the
+    // kernel is no better (worse).  Where it costs, the chains of this engine use the synchronous hand-over.
+    hipStream_t calibrated_for = nullptr;
+    bool calibrated = false;
+    bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
     unsigned long long wait_ticks = 10ull * 100000000ull; // bound of the chain's first packet (100 MHz ticks)
     std::atomic<int> queue_status{0};
@@ -448,7 +455,12 @@ AqlChain* aql_create(int hip_device, std::string* why)
     }
     if (ok) ok = hipDeviceSynchronize() == hipSuccess;
     if (ok) ok = hsa_signal_create(1, 0, nullptr, &ch->done) == HSA_STATUS_SUCCESS;
-    if (ok && c->concurrent_handover == 0) ch->sync_mode = true;
+    if (ok && c->concurrent_handover == 0) ch->sync_mode = ch->forced_sync = true;
+    if (ok && std::getenv("GYMRS_AQL_SYNC")) { // (developer knob: synchronous hand-over everywhere)
+        ch->sync_mode = ch->forced_sync = true;
+        std::lock_guard<std::mutex> lock(g_mu);
+        if (c->concurrent_handover < 0) c->concurrent_handover = 0;
+    }
     if (ok && c->concurrent_handover < 0) {
         // The asynchronous hand-over itself, once per device, on a stream of its own: begin -> end must let the stream through.
         // It needs a kernel of the stream and a kernel of the chain in flight TOGETHER; where they are not (rocprofv3 --pmc
@@ -473,7 +485,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
             } else {
                 std::lock_guard<std::mutex> lock(g_mu);
                 c->concurrent_handover = gave_up ? 0 : 1;
-                ch->sync_mode = gave_up != 0;
+                ch->sync_mode = ch->forced_sync = gave_up != 0;
             }
         }
         ch->wait_ticks = 10ull * 100000000ull;
@@ -578,6 +590,54 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
 }
 
 bool aql_is_synchronous(const AqlChain* c) { return c && c->sync_mode; }
+
+// Does the asynchronous hand-over suit THIS pair of queues (the stream's and the chain's)?  Three short chains of the counting
+// kernel each way on the engine's own stream, host clock around call + synchronise; the synchronous hand-over is taken when a
+// chain behind the sleeping kernel is clearly slower (> 1.25 x).  ~3 ms, once per engine and stream.
+const char* aql_calibrate(AqlChain* c, hipStream_t stream)
+{
+    if (c->forced_sync) return "synchronous (kernels of two queues do not run side by side here)";
+    static thread_local char note[160];
+    if (c->calibrated && c->calibrated_for == stream) return nullptr; // (unchanged)
+    c->calibrated = true;
+    c->calibrated_for = stream;
+    c->sync_mode = false;
+    if (const char* v = std::getenv("GYMRS_AQL_HANDOVER")) { // (developer knob: "kernel" / "sync")
+        c->sync_mode = v[0] == 's';
+        return c->sync_mode ? "synchronous (forced)" : "asynchronous (forced)";
+    }
+    float* x = nullptr;
+    constexpr uint32_t kN4 = 1u << 18; // 4 MB
+    if (hipMalloc(&x, (size_t)kN4 * 16) != hipSuccess) return "asynchronous (not calibrated)";
+    const AqlKernel k = c->ctx->kernels["gymrs_aql_selfcheck"];
+    struct {
+        float* x;
+        uint32_t n4;
+    } args{x, kN4};
+    std::string why;
+    auto time_chains = [&](bool sync) -> double {
+        c->sync_mode = sync;
+        double best = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {
+            if (hipStreamSynchronize(stream) != hipSuccess) return 1e30;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (!aql_begin(c, stream, &why)) return 1e30;
+            bool ok = true;
+            for (int t = 0; t < 128 && ok; ++t) ok = aql_dispatch(c, k, kN4, 256, &args, sizeof(args), &why);
+            if (!aql_end(c, stream, &why) || !ok) return 1e30;
+            if (hipStreamSynchronize(stream) != hipSuccess) return 1e30;
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            best = us < best ? us : best;
+        }
+        return best;
+    };
+    const double t_async = time_chains(false), t_sync = time_chains(true);
+    c->sync_mode = t_async > 1.25 * t_sync;
+    (void)hipFree(x);
+    std::snprintf(note, sizeof(note), "%s (128-launch probe chains: %.0f us asynchronous, %.0f us synchronous)",
+                  c->sync_mode ? "synchronous: a kernel on the stream's queue slows this chain's queue" : "asynchronous", t_async, t_sync);
+    return note;
+}
 
 uint32_t aql_take_error(AqlChain* c)
 {

@@ -152,7 +152,7 @@ struct gymrs_engine {
     // can use it; aql_why says why not when it stays NULL.
     AqlChain* aql = nullptr;
     bool aql_tried = false;
-    std::string aql_why;
+    std::string aql_why, aql_handover;
     uint64_t aql_chains = 0, aql_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t limit_elided_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t age_refreshes = 0, age_waits = 0, age_wait_ns = 0;
@@ -1297,6 +1297,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     if (e->reset_log && e->log_pending != 0 && e->log_vec != e->vec) {
         if (gymrs_status st = fold_reset_log(e)) return st;
     }
+    if (const char* how = aql_calibrate(e->aql, e->stream)) e->aql_handover = how;
     if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
         aql_destroy(e->aql);
@@ -1304,7 +1305,9 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         return GYMRS_OK;
     }
     *taken = true;
-    const int threads = step_threads_of(e->kind, e->n, e->vec);
+    int threads = step_threads_of(e->kind, e->n, e->vec);
+    if (const char* v = std::getenv("GYMRS_DEV_THREADS")) // (developer knob: 256 work-items per workgroup for CartPole chains)
+        if (e->kind == GYMRS_CARTPOLE && std::atoi(v) == kBlock) threads = kBlock;
     uint32_t last_hints = ~0u;
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
@@ -1931,8 +1934,8 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
     g.uint("max_episode_steps", max_episode_steps);
     // chains of per-step launches that went through the engine's own AQL dispatcher (gymrs_aql.h), and why not if none can
     g.uint("aql_chains", e->aql_chains).uint("aql_launches", e->aql_launches);
-    g.str("aql", e->aql ? (aql_is_synchronous(e->aql) ? "on (synchronous hand-over: kernels of two queues do not run side by side here)" : "on")
-                        : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
+    if (e->aql) g.str("aql_handover", e->aql_handover.c_str());
+    g.str("aql", e->aql ? "on" : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
     if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
         g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
         g.uint("time_limit_waits", e->age_waits).uint("time_limit_wait_us", e->age_wait_ns / 1000);

@@ -179,8 +179,14 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
 }
 
+#ifndef GYMRS_EXP_WAVES // (developer builds: the occupancy the register allocator aims for)
+#define GYMRS_EXP_WAVES(VEC_) (16 / (VEC_) < 1 ? 1 : 16 / (VEC_))
+#endif
+#ifndef GYMRS_EXP_WAVES_MIN
+#define GYMRS_EXP_WAVES_MIN 1
+#endif
 #define GYMRS_STEP_KERNEL_ATTRS(THREADS_, VEC_) \
-    __global__ __launch_bounds__(THREADS_) __attribute__((amdgpu_waves_per_eu(1, 16 / (VEC_) < 1 ? 1 : 16 / (VEC_))))
+    __global__ __launch_bounds__(THREADS_) __attribute__((amdgpu_waves_per_eu(GYMRS_EXP_WAVES_MIN, GYMRS_EXP_WAVES(VEC_))))
 
 template <class Env, int VEC, uint32_t FLAGS, int THREADS>
 GYMRS_STEP_KERNEL_ATTRS(THREADS, VEC) void step_kernel(float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast,

@@ -199,3 +199,42 @@ def test_full_size_chain_is_bit_identical_and_faster(gymrs):
     assert out[True][3]["aql_launches"] == 300 + 5 * steps and out[False][3]["aql_launches"] == 0
     print(f"us per 2^20-lane step: AQL chain {out[True][2]:.3f}, HIP launches {out[False][2]:.3f}")
     assert out[True][2] < out[False][2]
+
+
+def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
+    """Several engines = several chain queues next to several stream queues.  On some placements of a stream's queue and its
+    chain's queue the asynchronous hand-over (a one-wave kernel in flight on the stream while the chain runs) slows the chain
+    by a factor of 3-6 (profiles/r03_two_engines.log); every engine therefore times both hand-overs on its own stream once and
+    keeps the synchronous one where the asynchronous one costs.  Whatever each engine picked: same bits as the twin, and no
+    engine's chains are slower than twice the fastest engine's."""
+    import time
+
+    n, nbuf, steps = 1 << 18, 4, 400
+    flags = flags_of(gymrs, 0)
+    with aql(True):
+        engines = []
+        for k in range(3):
+            eng = gymrs.BatchedEngine(0, n, flags=flags, global_env_offset=k * n)
+            eng.reset(seed=11)
+            engines.append((eng, ring_for(eng, 0, n, nbuf)))
+        rates = [[] for _ in engines]
+        for rnd in range(4):
+            for k, (eng, ring) in enumerate(engines):
+                eng.sync()
+                t0 = time.perf_counter()
+                eng.step_many(ring.data_ptr(), n, nbuf, steps)
+                eng.sync()
+                rates[k].append((time.perf_counter() - t0) * 1e6 / steps)
+        best = [min(r[1:]) for r in rates]  # (the first round includes the calibration)
+        assert max(best) < 2.0 * min(best), rates
+        for k, (eng, ring) in enumerate(engines):
+            x = extras(eng)
+            assert x["aql"] == "on" and x["aql_launches"] == 4 * steps and x["aql_handover"], x
+            tw = TwinEngine(twin, 0, n, eng.params, flags=flags, gid0=k * n)
+            tw.reset(11)
+            bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+            for _ in range(4):
+                for t in range(steps):
+                    tw.step(bufs[t % nbuf])
+            assert same(eng.get_state(), tw.get_state()) and np.array_equal(eng.stats(), tw.stats())
+            eng.close()
