@@ -84,8 +84,11 @@ def test_the_drivers_own_command_reports_the_kernel_limited_rate():
     # (the copy probe is HIP-launched, release fence and all: a chain's step can be FASTER than the copy of its own footprint)
     assert 3000 < pm["hbm_copy_GBps"] < 8000 and 2.0 < pm["same_footprint_copy_us"] < 10.0
     assert 0.5 < d["roofline"]["frac_of_same_footprint_copy"] <= 1.6
-    assert d["config"]["submission"].startswith("AQL chains")  # the headline runs through the engine's own dispatcher
-    assert d["value"] >= 1.9e11, d["value"]
+    # the headline runs through the engine's own dispatcher; a box on which its self-check fails (no large-BAR access to device
+    # memory, ...) runs HIP launches, says why, and is held to round 2's rate
+    chained = d["config"]["submission"].startswith("AQL chains")
+    print("submission:", d["config"]["submission"])
+    assert d["value"] >= (1.9e11 if chained else 1.4e11), (d["value"], d["config"]["submission"])
 
 
 def test_default_form_prints_the_contract_line():
