@@ -136,20 +136,22 @@ def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     assert one["episodes"] == two["episodes"] and one["episodes"]["n_episodes"] > 0
 
 
-def test_eight_ranks_share_the_gpu(tmp_path):
-    """BASELINE configs[4]'s SHAPE on a 1-GPU box (VERDICT r2 "next" #1e): `--gpus 8 --oversubscribe` -- the plain form starts 8
+@pytest.mark.parametrize("lanes", [32768, 1 << 20])
+def test_eight_ranks_share_the_gpu(tmp_path, lanes):
+    """BASELINE configs[4]'s SHAPE on a 1-GPU box (VERDICT r2 "next" #1e; lanes = 2^20: its exact size, 2^23 lanes with global env ids
+    rank * 2^20 + i, eight chains on one GPU): `--gpus 8 --oversubscribe` -- the plain form starts 8
     ranks itself, each a shard with global env ids rank * n + i on cuda:0, gloo between them (RCCL refuses 8 ranks on one
     device).  The line carries 8 rank records, the roofline object and (short sample) the CPU baseline; the statistics equal
     ONE engine of 8n lanes run through the same schedule."""
     common = ["--steps", "30", "--warmup", "10", "--no-probe", "--repetitions", "5", "--action-buffers", "8"]
     env = dict(os.environ, GYMRS_BENCH_PASSES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    eight = run([sys.executable, "bench.py", "--gpus", "8", "--oversubscribe", "--n-envs", "32768", "--cpu-seconds", "1", *common], env=env)
+    eight = run([sys.executable, "bench.py", "--gpus", "8", "--oversubscribe", "--n-envs", str(lanes), "--cpu-seconds", "1", *common], env=env)
     check_common(eight, 8, 30, 10, min_ms=0.0, min_frac=0.0)  # (8 small shards taking turns on one GPU: not a rate)
     assert eight["oversubscribed"] and eight["config"]["stats_allreduce"] == "torch.distributed(gloo)"
-    assert len(eight["ranks"]) == 8 and eight["config"]["total_lanes"] == 8 * 32768
+    assert len(eight["ranks"]) == 8 and eight["config"]["total_lanes"] == 8 * lanes
     assert eight["cpu_baseline"]["kind"] == "port" and eight["cpu_baseline"]["value"] > 1e6  # an N > 1 line carries it too
     assert eight["roofline"]["bound"] == "hbm" and eight["config"]["comm_watchdog"] == "not triggered"
-    one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", str(8 * 32768), "--cpu-seconds", "0", *common], env=env)
+    one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", str(8 * lanes), "--cpu-seconds", "0", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == eight["timing"]["passes_per_repetition"] == 2
     assert one["timing"]["calibration_passes"] == eight["timing"]["calibration_passes"]
     assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0
