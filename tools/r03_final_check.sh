@@ -5,7 +5,7 @@ OUT=gpurun_out/r03_final
 mkdir -p $OUT
 python -m pytest tests/ -x -q -m gpu > $OUT/pytest.log 2>&1; echo "pytest rc=$? $(grep -E 'passed|failed' $OUT/pytest.log | tail -1)"
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$? $(tail -1 $OUT/smoke.log | cut -c1-160)"
-/usr/bin/time -f "bench wall %e s" python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -1 $OUT/bench.err
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -1 $OUT/bench.err
 python - <<'PY'
 import json
 d=json.load(open("gpurun_out/r03_final/bench.json"))
