@@ -286,37 +286,52 @@ def load_pmc(name: str, env: str, sha: str):
 
 
 def measure_pmc_traffic(args, env_name: str, sha: str):
-    """Two short rocprofv3 --pmc passes of this very command (one counter per pass, counters only), read back from the
-    rocpd databases; FETCH_SIZE doubled as the guide's gfx950 correction for wide coalesced reads prescribes."""
+    """Short rocprofv3 --pmc passes of this very command (one counter per pass, counters only), read back from the rocpd databases;
+    FETCH_SIZE doubled as the guide's gfx950 correction for wide coalesced reads prescribes.  Two submission paths, two passes each:
+      * "chain": the chain's own kernel.  rocprofv3's counter collection serialises kernels across queues, so the chains run with the
+        SYNCHRONOUS hand-over there (GYMRS_AQL_SYNC=1: no kernel of the stream in flight next to the chain) -- and what the profiler
+        does between two serialised kernels is outside the kernel's counter window: lines the kernel leaves dirty in the L2s (its state
+        stores, by design) are not in its WRITE_SIZE;
+      * "hip": the same code launched through HIP (GYMRS_AQL=0), every access hinted, a release fence inside every launch's window."""
     import sqlite3
     import subprocess
     import tempfile
 
-    out = {}
+    recs = {}
     note = None
     with tempfile.TemporaryDirectory(prefix="gymrs_pmc_", dir="/tmp") as tmp:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = Path(tmp) / ctr
-            cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
-                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
-            if args.n_envs:
-                cmd += ["--n-envs", str(args.n_envs)]
-            if args.vec:
-                cmd += ["--vec", str(args.vec)]
-            env = dict(os.environ, TMPDIR="/tmp")
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
-            dbs = list(d.rglob("*_results.db"))
-            if res.returncode != 0 or not dbs:
-                return None, f"rocprofv3 --pmc {ctr} failed (rc {res.returncode}): {res.stderr[-300:]}"
-            c = sqlite3.connect(str(dbs[0]))
-            # (the per-step kernel under either name: HIP's template instance, or the chain's copy in the stand-alone code object)
-            r = c.execute("select count(*), avg(value) from counters_collection where (kernel_name like '%step_kernel%' or "
-                          "kernel_name like ?) and counter_name = ?", (f"gymrs_aql_{env_name}_t%", ctr)).fetchone()
-            out[ctr] = {"launches": r[0], "avg_kb": r[1]}
-    fetch = 2.0 * out["FETCH_SIZE"]["avg_kb"] * 1024.0
-    write = out["WRITE_SIZE"]["avg_kb"] * 1024.0
-    rec = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "raw": out,
-           "correction": "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported"}
+        for path_name, path_env in (("chain", {"GYMRS_AQL": "1", "GYMRS_AQL_SYNC": "1"}), ("hip", {"GYMRS_AQL": "0"})):
+            out = {}
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = Path(tmp) / f"{path_name}_{ctr}"
+                cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
+                       "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
+                if args.n_envs:
+                    cmd += ["--n-envs", str(args.n_envs)]
+                if args.vec:
+                    cmd += ["--vec", str(args.vec)]
+                env = dict(os.environ, TMPDIR="/tmp", **path_env)
+                res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+                dbs = list(d.rglob("*_results.db"))
+                if res.returncode != 0 or not dbs:
+                    return None, f"rocprofv3 --pmc {ctr} ({path_name}) failed (rc {res.returncode}): {res.stderr[-300:]}"
+                c = sqlite3.connect(str(dbs[0]))
+                like = f"gymrs_aql_{env_name}_t%" if path_name == "chain" else "%step_kernel%"
+                r = c.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and counter_name = ?", (like, ctr)).fetchone()
+                out[ctr] = {"launches": r[0], "avg_kb": r[1]}
+            if not out["FETCH_SIZE"]["launches"] or not out["WRITE_SIZE"]["launches"]:
+                continue  # (that path did not run under the profiler: e.g. no chains on this box)
+            fetch = 2.0 * out["FETCH_SIZE"]["avg_kb"] * 1024.0
+            write = out["WRITE_SIZE"]["avg_kb"] * 1024.0
+            recs[path_name] = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "raw": out}
+    if "hip" not in recs:
+        return None, "rocprofv3 --pmc: no launch of the step kernel was counted"
+    rec = dict(recs["hip"])  # (top level = the HIP-launched kernel, as in rounds 1-2)
+    rec["correction"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported"
+    if "chain" in recs:
+        rec["chain"] = recs["chain"]
+        rec["chain"]["note"] = ("the chain's own kernel, counted under rocprofv3's serialisation with the synchronous hand-over; lines still dirty in the "
+                                "L2s when the kernel ends (its state stores) are written back outside its counter window")
     path = ROOT / "profiles" / "pmc_traffic.json"
     try:
         data = json.loads(path.read_text())
@@ -544,10 +559,14 @@ def run_rank(args, info, backend, make_collective=None):
             if note:
                 roof["traffic_note"] = note
             if traffic and submission and submission.startswith("AQL"):
-                roof["traffic_measured_on"] = ("the same kernel launched through HIP with every access hinted: rocprofv3's counter collection "
-                                               "serialises kernels across queues, which a chain's hand-over cannot live with (the dispatcher's "
-                                               "self-check then sends the launches through HIP); the chain's own variant streams only the state "
-                                               "loads and the stores nobody reads again, and leaves its state stores in the L2s")
+                roof["traffic_measured_on"] = ("the same kernel launched through HIP (every access hinted, a release fence inside every launch's "
+                                               "counter window): what the step moves when nothing stays in the L2s between launches")
+                chain_t = (rec_t or {}).get("chain")
+                if chain_t:
+                    # the chain's own kernel (PMC under rocprofv3's serialisation, synchronous hand-over): its state stores are still in the
+                    # L2s when it ends, so its window holds the reads and the streamed stores only
+                    roof["traffic_chain_kernel"] = {"bytes_per_launch": chain_t["bytes_per_launch"], "fetch_bytes": chain_t["fetch_bytes"],
+                                                    "write_bytes": chain_t["write_bytes"], "note": chain_t.get("note")}
             if traffic:
                 # what is MOVED next to what is COUNTED: MountainCar elides its constant reward store, Pendulum's theta_dot
                 # observation column aliases the state column
