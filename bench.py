@@ -543,6 +543,10 @@ def run_rank(args, info, backend, make_collective=None):
         if getattr(backend, "oversubscribed", False):
             out["oversubscribed"] = "TEST RUN: ranks share GPUs and meet over gloo; value is not a benchmark result"
         roof = out["roofline"]
+        if roof["frac"] > 1.0:
+            roof["frac_note"] = ("above 1: at this size one step's arrays (%.0f MB) stay in the L2s (32 MB) and the Infinity Cache (256 MB) -- inside a chain "
+                                 "not even the state leaves the L2s between launches -- so the algorithmic bytes move faster than HBM could deliver them; the "
+                                 "HBM-streaming figure of the same path is configs.cartpole_2p24_dram_resident" % (n * bytes_per_step / 1e6))
         if not args.rollout:
             # traffic: measured by this run (--pmc-traffic) or the committed figure if it belongs to these kernels
             traffic, note = (None, None)
