@@ -254,3 +254,68 @@ def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
                     tw.step(bufs[t % nbuf])
             assert same(eng.get_state(), tw.get_state()) and np.array_equal(eng.stats(), tw.stats())
             eng.close()
+
+
+@pytest.mark.parametrize("kind,steps", [(2, 450), (0, 300), (1, 450)])
+def test_long_chains_forced_hints_reset_and_restore(gymrs, twin, kind, steps):
+    """Chains that cross Pendulum's 200-step time limit twice (the host-computed truncate_all argument changes inside a chain), with
+    the memory hint forced both ways (gymrs_set_tuning: the `_nt` and `_pl` kernel variants), a seeded reset, stats_clear and a
+    snapshot restore between chains: bits and statistics of the twin every time."""
+    n, nbuf = 9001, 6
+    flags = flags_of(gymrs, kind)
+    with aql(True):
+        eng = gymrs.BatchedEngine(kind, n, flags=flags, global_env_offset=77)
+        tw = TwinEngine(twin, kind, n, eng.params, flags=flags, gid0=77)
+        eng.reset(seed=21)
+        tw.reset(21)
+        ring = ring_for(eng, kind, n, nbuf)
+        bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+        stride = ring.stride(0) * ring.element_size()
+
+        def both(k):
+            eng.step_many(ring.data_ptr(), stride, nbuf, k)
+            for t in range(k):
+                tw.step(bufs[t % nbuf])
+
+        def stats_equal(gs, ts):  # Pendulum's sum of returns is a float sum over waves: the order differs from the twin's
+            return (np.array_equal(gs[1:], ts[1:]) and gs[0] == pytest.approx(ts[0], rel=1e-5)) if kind == 2 else np.array_equal(gs, ts)
+
+        def check(what):
+            assert same(eng.get_state(), tw.get_state()), what
+            assert stats_equal(eng.stats(), tw.stats()), (what, eng.stats(), tw.stats())
+            r, d, tr = eng.get_step_result()
+            tr_, td, tt = tw.get_result()
+            assert np.array_equal(d, td) and np.array_equal(tr, tt) and same(r, tr_), what
+
+        both(steps)
+        check("automatic hints")
+        eng.set_tuning(4, 1)   # every access hinted
+        both(steps // 2)
+        check("forced non-temporal")
+        eng.set_tuning(4, 2)   # none
+        both(steps // 2)
+        check("forced plain")
+        eng.set_tuning(4, 0)
+        blob = eng.snapshot()
+        tw_state, tw_stats = tw.get_state().copy(), tw.stats().copy()
+        both(40)
+        eng.restore(blob)      # back to the snapshot: the twin is rebuilt to the same point by replaying
+        tw2 = TwinEngine(twin, kind, n, eng.params, flags=flags, gid0=77)
+        tw2.reset(21)
+        for k in (steps, steps // 2, steps // 2):
+            for t in range(k):
+                tw2.step(bufs[t % nbuf])
+        assert same(tw2.get_state(), tw_state) and np.array_equal(tw2.stats(), tw_stats)
+        assert same(eng.get_state(), tw_state) and stats_equal(eng.stats(), tw_stats)
+        tw = tw2
+        both(33)
+        check("after the restore")
+        eng.stats_clear()
+        tw.stats_clear()
+        eng.reset(seed=5)
+        tw.reset(5)
+        both(64)
+        check("after stats_clear + reset")
+        x = extras(eng)
+        assert x["aql"] == "on" and x["aql_launches"] == steps + 2 * (steps // 2) + 40 + 33 + 64, x
+        eng.close()
