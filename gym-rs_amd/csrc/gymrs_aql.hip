@@ -96,6 +96,9 @@ struct DeviceCtx {
     hsa_executable_t exe{};
     std::map<std::string, AqlKernel> kernels;
     int concurrent_handover = -1; // -1 not tried yet, 1 works, 0 kernels of two queues do not run side by side here (see aql_create)
+    // bumped whenever a chain object of this device is created or destroyed: which hand-over suits an engine depends on where its
+    // queues sit among the process's queues, so every engine looks again (aql_calibrate, ~3 ms) when the set of chains has changed
+    std::atomic<uint32_t> epoch{0};
 };
 
 constexpr int kMaxDevices = 64;
@@ -171,6 +174,7 @@ public:
     // kernel is no better (worse).  Where it costs, the chains of this engine use the synchronous hand-over.
     hipStream_t calibrated_for = nullptr;
     bool calibrated = false;
+    uint32_t calibrated_epoch = 0;
     bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
     unsigned long long wait_ticks = 10ull * 100000000ull; // bound of the chain's first packet (100 MHz ticks)
@@ -495,12 +499,14 @@ AqlChain* aql_create(int hip_device, std::string* why)
         if (why->find("hand-over self-check") == std::string::npos) aql_destroy(ch);
         return nullptr;
     }
+    c->epoch.fetch_add(1, std::memory_order_relaxed);
     return ch;
 }
 
 void aql_destroy(AqlChain* c)
 {
     if (!c) return;
+    if (c->ctx) c->ctx->epoch.fetch_add(1, std::memory_order_relaxed);
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
@@ -598,9 +604,11 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream)
 {
     if (c->forced_sync) return "synchronous (kernels of two queues do not run side by side here)";
     static thread_local char note[160];
-    if (c->calibrated && c->calibrated_for == stream) return nullptr; // (unchanged)
+    const uint32_t epoch = c->ctx->epoch.load(std::memory_order_relaxed);
+    if (c->calibrated && c->calibrated_for == stream && c->calibrated_epoch == epoch) return nullptr; // (unchanged)
     c->calibrated = true;
     c->calibrated_for = stream;
+    c->calibrated_epoch = epoch;
     c->sync_mode = false;
     if (const char* v = std::getenv("GYMRS_AQL_HANDOVER")) { // (developer knob: "kernel" / "sync")
         c->sync_mode = v[0] == 's';

@@ -28,6 +28,16 @@ def run(e, ring, label):
 
 order = sys.argv[1] if len(sys.argv) > 1 else "ab"
 A, ra = make()
+if order == "late":  # A steps while it is the only engine; B and C appear later: A has to look at its hand-over again
+    run(A, ra, "A alone")
+    B, rb = make()
+    C, rc = make()
+    run(B, rb, "B (created after A stepped)"); run(C, rc, "C"); run(A, ra, "A again, now one of three"); run(B, rb, "B again")
+    C.close(); B.close()
+    run(A, ra, "A alone again")
+    import json
+    print("A", json.loads(A.env_json(0))["gymrs"].get("aql_handover"))
+    sys.exit(0)
 B, rb = make()
 if order == "ab":
     run(A, ra, "A (created first), first chains"); run(B, rb, "B (created second)"); run(A, ra, "A again"); run(B, rb, "B again")
