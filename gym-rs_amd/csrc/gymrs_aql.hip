@@ -268,7 +268,8 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
     std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
-    for (const char* stem : {"gymrs_aql_cartpole_t512", "gymrs_aql_cartpole_t256", "gymrs_aql_mountain_car_t256", "gymrs_aql_pendulum_t256"})
+    for (const char* stem : {"gymrs_aql_cartpole_t512", "gymrs_aql_cartpole_t256", "gymrs_aql_cartpole_lim_t512", "gymrs_aql_cartpole_lim_t256",
+                             "gymrs_aql_mountain_car_t256", "gymrs_aql_pendulum_t256"})
         for (const char* hint : {"_nt", "_o", "_so", "_pl"}) names.push_back(std::string(stem) + hint);
     for (const std::string& name : names) {
         const char* nm = name.c_str();

@@ -152,6 +152,7 @@ struct gymrs_engine {
     // can use it; aql_why says why not when it stays NULL.
     AqlChain* aql = nullptr;
     bool aql_tried = false;
+    bool chain_open = false; // gymrs_step_many is inside aql_begin .. aql_end: see stream_op_barrier
     std::string aql_why, aql_handover;
     uint64_t aql_chains = 0, aql_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t limit_elided_launches = 0; // for the serde view's engine extras (tests, diagnostics)
@@ -285,6 +286,20 @@ static StatsArgs stats_args(const gymrs_engine* e)
     return a;
 }
 
+// A chain of per-step launches (gymrs_aql.h) runs on the engine's own queue; until it is closed the engine's HIP stream is not
+// held back, and what the chain wrote may still sit dirty in the L2s.  Whatever the host side of a step has to put on the
+// stream in mid-call -- the stand-alone fold of the reset log, a refresh of the time-limit bound, the memset of `truncated` --
+// therefore first closes the open chain (release + hand-over); step_many_aql opens the next one behind it.
+static gymrs_status stream_op_barrier(gymrs_engine* e)
+{
+    if (!e->chain_open) return GYMRS_OK;
+    e->chain_open = false;
+    std::string err;
+    if (!aql_end(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
+    e->aql_chains += 1;
+    return GYMRS_OK;
+}
+
 // ---- reset log bookkeeping (host side) ----------------------------------------------------------------------------
 // Invariant: the rows of the steps log_first_tick .. log_first_tick + log_pending - 1 (log_pending < kResetLogRows) may hold
 // bits; every other row of the ring is zero.
@@ -293,6 +308,7 @@ static StatsArgs stats_args(const gymrs_engine* e)
 static gymrs_status fold_reset_log(gymrs_engine* e)
 {
     if (!e->reset_log || e->log_pending == 0) return GYMRS_OK;
+    if (gymrs_status st = stream_op_barrier(e)) return st;
     HIP_TRY(launch_fold_reset_log(e->reset_log, e->log_row_words, e->log_first_tick, e->log_pending, e->log_vec, e->ep_start, e->n,
                                   e->block_stats, e->stream));
     e->log_pending = 0;
@@ -351,7 +367,9 @@ static void limit_restart(gymrs_engine* e, uint64_t bound, bool trunc_zero)
 // answer is not there after kAgeWaitNs: the caller then launches the kernel WITH the limit, which is always correct
 // (a caller-provided stream may be blocked on work this very thread has not submitted yet -- an event it
 // records later, a capture -- and an unbounded spin would never end).
-constexpr uint64_t kAgeWaitNs = 2'000'000; // ~300 launches of the headline kernel
+constexpr uint64_t kAgeWaitNs = 2'000'000;        // a caller-provided stream (it may be blocked on work nobody has submitted yet): ~300 headline launches
+constexpr uint64_t kAgeWaitOwnNs = 200'000'000;   // the engine's own stream always drains: long enough for a whole chain segment (the host runs
+                                                  // thousands of launches ahead of the device inside a chain), short enough to notice a dead device
 static gymrs_status wait_for_age(gymrs_engine* e, bool* arrived)
 {
     const auto t0 = std::chrono::steady_clock::now();
@@ -362,7 +380,8 @@ static gymrs_status wait_for_age(gymrs_engine* e, bool* arrived)
             if (q != hipSuccess && q != hipErrorNotReady) return fail(GYMRS_EHIP, std::string("time-limit refresh: ") + hipGetErrorString(q));
             if (q == hipSuccess && e->age_host[1] != e->age_seq)
                 return fail(GYMRS_EHIP, "time-limit refresh: the stream is idle but the result never arrived");
-            if ((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kAgeWaitNs) {
+            if ((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() >
+                (e->own_stream ? kAgeWaitOwnNs : kAgeWaitNs)) {
                 *arrived = false;
                 return GYMRS_OK;
             }
@@ -431,6 +450,7 @@ static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
         adopt();
     }
     if (e->age_pending && !e->age_gave_up && e->tick + 1 - e->start_bound >= limit) { // the answer decides THIS launch
+        if (gymrs_status st = stream_op_barrier(e)) return st; // (the refresh sits on the stream BEHIND the open chain's hand-over)
         const auto t0 = std::chrono::steady_clock::now();
         bool arrived = false;
         if (gymrs_status st = wait_for_age(e, &arrived)) return st;
@@ -459,6 +479,7 @@ static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
         }
     }
     if (refresh) {
+        if (gymrs_status st = stream_op_barrier(e)) return st;
         e->age_seq += 1;
         HIP_TRY(launch_max_age(e->ep_start, e->n, (uint32_t)e->tick, e->age_dev, e->age_host_dev, e->age_seq, e->stream));
         e->age_pending = true;
@@ -468,6 +489,7 @@ static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
     if (!reachable) {
         flags &= ~(uint32_t)GYMRS_TIME_LIMIT;
         if (!e->trunc_zero) { // the last launch with the limit may have left ones behind
+            if (gymrs_status st = stream_op_barrier(e)) return st;
             HIP_TRY(hipMemsetAsync(e->truncated, 0, (size_t)e->n, e->stream));
             e->trunc_zero = true;
         }
@@ -1226,7 +1248,10 @@ static std::string aql_kernel_name(const gymrs_engine* e, uint32_t flags, int th
     const uint32_t f = flags & (A | S | T);
     const char* stem = nullptr;
     switch (e->kind) {
-    case GYMRS_CARTPOLE: stem = f == (A | S) ? (threads == kCartPoleThreads ? "gymrs_aql_cartpole_t512" : "gymrs_aql_cartpole_t256") : nullptr; break;
+    case GYMRS_CARTPOLE: // (A|S|T: the launches of a limit-eliding engine that do have to check the limit, flags_for_step)
+        if (f == (A | S)) stem = threads == kCartPoleThreads ? "gymrs_aql_cartpole_t512" : "gymrs_aql_cartpole_t256";
+        if (f == (A | S | T)) stem = threads == kCartPoleThreads ? "gymrs_aql_cartpole_lim_t512" : "gymrs_aql_cartpole_lim_t256";
+        break;
     case GYMRS_MOUNTAIN_CAR: stem = f == (A | S) ? "gymrs_aql_mountain_car_t256" : nullptr; break;
     case GYMRS_PENDULUM: stem = f == (A | S | T) ? "gymrs_aql_pendulum_t256" : nullptr; break;
     }
@@ -1253,7 +1278,7 @@ static uint32_t chain_hint_bits(const gymrs_engine* e)
 
 static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
 {
-    if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host || e->limit_elidable) return false;
+    if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host) return false;
     if (const char* v = std::getenv("GYMRS_AQL")) // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
         if (v[0] == '0') return false;
     if (aql_kernel_name(e, e->flags, kBlock).empty()) return false;
@@ -1298,35 +1323,43 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         if (gymrs_status st = fold_reset_log(e)) return st;
     }
     if (const char* how = aql_calibrate(e->aql, e->stream)) e->aql_handover = how;
-    if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched: this engine goes back to HIP launches for good
+    if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched, no host state touched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
         aql_destroy(e->aql);
         e->aql = nullptr;
         return GYMRS_OK;
     }
+    e->chain_open = true;
     *taken = true;
     int threads = step_threads_of(e->kind, e->n, e->vec);
     if (const char* v = std::getenv("GYMRS_DEV_THREADS")) // (developer knob: 256 work-items per workgroup for CartPole chains)
         if (e->kind == GYMRS_CARTPOLE && std::atoi(v) == kBlock) threads = kBlock;
-    uint32_t last_hints = ~0u;
+    uint32_t last_key = ~0u;
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
         const std::string msg = g_last_error;
-        std::string ignored;
-        (void)aql_end(e->aql, e->stream, &ignored);
+        (void)stream_op_barrier(e);
         g_last_error = msg;
         return st;
     };
     for (uint32_t t = first; t < n_steps; ++t) {
+        // The host side of the step first: on an engine that elides its time limit it may have to put something on the stream (a
+        // refresh of the bound, a memset, the stand-alone fold) or wait for the device -- each of which closes the open chain
+        // (stream_op_barrier).  The step itself then goes into the open chain, or into a new one behind whatever that was.
         uint32_t flags = 0;
         if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
         flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
-        if ((flags & kFlagHintMask) != last_hints) {
+        if (!e->chain_open) { // (the host side of this step closed the chain: the step opens the next one)
+            if (!aql_begin(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
+            e->chain_open = true;
+        }
+        const uint32_t key = (flags & kFlagHintMask) | (flags & GYMRS_TIME_LIMIT);
+        if (key != last_key) {
             const std::string name = aql_kernel_name(e, flags, threads);
             if (name.empty() || !aql_kernel(e->aql, name.c_str(), &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));
-            last_hints = flags & kFlagHintMask;
+            last_key = key;
         }
         bool ok = false;
         switch (e->kind) {
@@ -1340,9 +1373,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
         e->aql_launches += 1;
     }
-    if (!aql_end(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
-    e->aql_chains += 1;
-    return GYMRS_OK;
+    return stream_op_barrier(e);
 }
 
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes, uint32_t n_buffers,

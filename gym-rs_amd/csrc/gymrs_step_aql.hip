@@ -6,7 +6,7 @@
 // only on its last one -- tile i is stepped by workgroup i, hence by the same XCD and the same L2, in every launch.
 // Same templates, same flags, same code as the kernels HIP launches (gymrs_step_<env>.hip): same bits.
 // Only the flag sets the BASELINE configs run (lanes-per-work-item 4; CartPole / MountainCar AUTO_RESET|TRACK_STATS, Pendulum
-// + TIME_LIMIT; hinted and plain accesses); every other launch goes through HIP as before.
+// + TIME_LIMIT) and CartPole with all three flags; every other launch goes through HIP as before.
 #include "gymrs_step_impl.h"
 
 using namespace gymrs;
@@ -27,6 +27,9 @@ constexpr uint32_t kAS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, kAST = kAS | GYMR
     GYMRS_AQL_STEP(PREFIX_##_pl, ENV_, (FLAGS_), THREADS_)
 GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t512, CartPoleT, kAS, 512)
 GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t256, CartPoleT, kAS, 256)
+// (CartPole with all three flags = Gym's CartPole-v1 with its 500-step cap: the launches of a limit-eliding engine that DO check the limit)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_lim_t512, CartPoleT, kAST, 512)
+GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_lim_t256, CartPoleT, kAST, 256)
 GYMRS_AQL_STEP_HINTS(gymrs_aql_mountain_car_t256, MountainCarT, kAS, 256)
 GYMRS_AQL_STEP_HINTS(gymrs_aql_pendulum_t256, PendulumT, kAST, 256)
 

@@ -175,8 +175,10 @@ def test_full_size_long_run_statistics(gymrs):
     assert np.array_equal(a.get_state().view(np.uint32), b.get_state().view(np.uint32))
     _, _, tr = a.get_step_result()
     assert not tr.any()
-    # (a launch checks the limit itself when the refresh it would need has not arrived after a bounded wait: a handful per run)
-    assert json.loads(a.env_json(0))["gymrs"]["time_limit_elided_launches"] >= steps - 32
+    # (a launch checks the limit itself when the refresh it would need has not arrived after a bounded wait -- inside a chain the
+    # host runs far ahead of the device, so each approach to the bound costs a few such launches: a few per cent of a run)
+    x = json.loads(a.env_json(0))["gymrs"]
+    assert x["time_limit_elided_launches"] >= 0.9 * steps, x
     a.close()
     b.close()
 
