@@ -128,7 +128,7 @@ def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     common = ["--steps", "40", "--warmup", "10", "--cpu-seconds", "0", "--no-probe", "--repetitions", "5", "--action-buffers", "8"]
     env = dict(os.environ, GYMRS_BENCH_PASSES="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = run([sys.executable, "bench.py", "--gpus", "2", "--oversubscribe", "--n-envs", "100000", *common], env=env)
-    check_common(two, 2, 40, 10, min_ms=0.0)  # GYMRS_BENCH_PASSES pins the work so that the two runs are comparable
+    check_common(two, 2, 40, 10, min_ms=0.0, min_frac=0.0)  # GYMRS_BENCH_PASSES pins the work so that the two runs are comparable
     assert two["oversubscribed"] and two["config"]["stats_allreduce"] == "torch.distributed(gloo)"
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", "200000", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == two["timing"]["passes_per_repetition"] == 3
