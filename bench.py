@@ -89,7 +89,7 @@ def kernel_name(env: str, vec: int, flags: int, n: int, submission):
     per_step = n * (state_dim * 8 + 10 + (8 if env == "pendulum" else 0))
     hint = "_nt" if per_step >= (340 << 20) else ("_so" if per_step <= (48 << 20) else "_o")
     threads = 512 if env == "cartpole" and n >= 512 * vec * 512 else 256
-    return "gymrs_aql_%s_t%d%s (= step_kernel_body<%s, %d, flags=%d> in the chain's code object)" % (env, threads, hint, env, vec, flags)
+    return "gymrs_aql_%s_f%d_t%d%s (= step_kernel_body<%s, %d, flags=%d> in the chain's code object)" % (env, flags & 7, threads, hint, env, vec, flags)
 
 
 def cpu_baseline(kind: int, target_seconds: float):

@@ -268,9 +268,13 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
     std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
-    for (const char* stem : {"gymrs_aql_cartpole_t512", "gymrs_aql_cartpole_t256", "gymrs_aql_cartpole_lim_t512", "gymrs_aql_cartpole_lim_t256",
-                             "gymrs_aql_mountain_car_t256", "gymrs_aql_pendulum_t256"})
-        for (const char* hint : {"_nt", "_o", "_so", "_pl"}) names.push_back(std::string(stem) + hint);
+    for (const char* env_threads : {"cartpole_f%d_t512", "cartpole_f%d_t256", "mountain_car_f%d_t256", "pendulum_f%d_t256"}) // (gymrs_step_aql.hip)
+        for (int flags : {0, 1, 3, 4, 5, 7})
+            for (const char* hint : {"_nt", "_o", "_so", "_pl"}) {
+                char stem[64];
+                std::snprintf(stem, sizeof(stem), env_threads, flags);
+                names.push_back(std::string("gymrs_aql_") + stem + hint);
+            }
     for (const std::string& name : names) {
         const char* nm = name.c_str();
         hsa_executable_symbol_t sym;

@@ -1236,7 +1236,7 @@ static gymrs_status build_graph(gymrs_engine* e, const char* base, uint64_t stri
 }
 
 // ---- chains of per-step launches through the engine's own AQL dispatcher (gymrs_aql.h) ---------------------------------
-// Which launches it takes: the flag sets the stand-alone code object holds (gymrs_step_aql.hip) at 4 lanes per work-item, on
+// Which launches it takes: every flag set at 4 lanes per work-item (what the stand-alone code object holds, gymrs_step_aql.hip), on
 // engines whose arrays live in device memory; chains of at least kAqlMinChain steps (a chain costs three small packets and two
 // stream operations of its own).  Everything else -- and every device on which the dispatcher's self-check fails -- goes
 // through HIP launches.
@@ -1245,20 +1245,15 @@ constexpr uint32_t kAqlMinChain = 8;
 static std::string aql_kernel_name(const gymrs_engine* e, uint32_t flags, int threads)
 {
     constexpr uint32_t A = GYMRS_AUTO_RESET, S = GYMRS_TRACK_STATS, T = GYMRS_TIME_LIMIT;
-    const uint32_t f = flags & (A | S | T);
-    const char* stem = nullptr;
-    switch (e->kind) {
-    case GYMRS_CARTPOLE: // (A|S|T: the launches of a limit-eliding engine that do have to check the limit, flags_for_step)
-        if (f == (A | S)) stem = threads == kCartPoleThreads ? "gymrs_aql_cartpole_t512" : "gymrs_aql_cartpole_t256";
-        if (f == (A | S | T)) stem = threads == kCartPoleThreads ? "gymrs_aql_cartpole_lim_t512" : "gymrs_aql_cartpole_lim_t256";
-        break;
-    case GYMRS_MOUNTAIN_CAR: stem = f == (A | S) ? "gymrs_aql_mountain_car_t256" : nullptr; break;
-    case GYMRS_PENDULUM: stem = f == (A | S | T) ? "gymrs_aql_pendulum_t256" : nullptr; break;
-    }
-    if (!stem) return std::string();
+    uint32_t f = flags & (A | S | T);
+    if (!(f & A)) f &= ~S; // statistics need auto-reset (as in the launch table, gymrs_step_impl.h)
+    const char* env = e->kind == GYMRS_CARTPOLE ? "cartpole" : (e->kind == GYMRS_MOUNTAIN_CAR ? "mountain_car" : "pendulum");
     const uint32_t h = flags & kFlagHintMask;
     const char* hint = (h & kFlagNonTemporal) ? "_nt" : (h == (kFlagNtOut | kFlagNtStateLoads) ? "_so" : (h == kFlagNtOut ? "_o" : (h == 0 ? "_pl" : nullptr)));
-    return hint ? std::string(stem) + hint : std::string();
+    if (!hint) return std::string();
+    char name[96];
+    std::snprintf(name, sizeof(name), "gymrs_aql_%s_f%u_t%d%s", env, f, threads, hint); // (the names of gymrs_step_aql.hip)
+    return name;
 }
 
 // Memory hints of a chain's launches (profiles/r03_chain_hints.log; us per step, chain with plain / out / state-loads+out hints):
@@ -1281,7 +1276,6 @@ static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
     if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host) return false;
     if (const char* v = std::getenv("GYMRS_AQL")) // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
         if (v[0] == '0') return false;
-    if (aql_kernel_name(e, e->flags, kBlock).empty()) return false;
     if (!e->own_stream) { // a caller-provided stream may be under a capture: a chain cannot be captured
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(e->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
@@ -1355,7 +1349,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
             if (!aql_begin(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
             e->chain_open = true;
         }
-        const uint32_t key = (flags & kFlagHintMask) | (flags & GYMRS_TIME_LIMIT);
+        const uint32_t key = (flags & kFlagHintMask) | (flags & (GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT));
         if (key != last_key) {
             const std::string name = aql_kernel_name(e, flags, threads);
             if (name.empty() || !aql_kernel(e->aql, name.c_str(), &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));

@@ -5,8 +5,9 @@
 // 2^20-lane steps 1.6-1.9 us per launch (profiles/r03_aql_probe.log); a chain of gymrs_step_many launches needs that fence
 // only on its last one -- tile i is stepped by workgroup i, hence by the same XCD and the same L2, in every launch.
 // Same templates, same flags, same code as the kernels HIP launches (gymrs_step_<env>.hip): same bits.
-// Only the flag sets the BASELINE configs run (lanes-per-work-item 4; CartPole / MountainCar AUTO_RESET|TRACK_STATS, Pendulum
-// + TIME_LIMIT) and CartPole with all three flags; every other launch goes through HIP as before.
+// Every flag set of the launch table at 4 lanes per work-item (8 lanes per work-item is a tuning knob and stays on HIP launches), named
+//   gymrs_aql_<env>_f<AUTO_RESET | TRACK_STATS | TIME_LIMIT as a number>_t<work-items per workgroup>_<hint variant>
+// (TRACK_STATS without AUTO_RESET does not exist: the launch table drops it, and so does the engine before it asks for a name).
 #include "gymrs_step_impl.h"
 
 using namespace gymrs;
@@ -18,20 +19,24 @@ using namespace gymrs;
         step_kernel_body<ENV_, 4, FLAGS_, THREADS_>(s0, s1, s2, s3, action, n_fast, rest, c);                                             \
     }
 
-constexpr uint32_t kAS = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, kAST = kAS | GYMRS_TIME_LIMIT;
 // hint variants: _nt every access, _o only the stores nobody reads again, _so those plus the state loads, _pl none
 #define GYMRS_AQL_STEP_HINTS(PREFIX_, ENV_, FLAGS_, THREADS_)                     \
     GYMRS_AQL_STEP(PREFIX_##_nt, ENV_, (FLAGS_) | kFlagNonTemporal, THREADS_)     \
     GYMRS_AQL_STEP(PREFIX_##_o, ENV_, (FLAGS_) | kFlagNtOut, THREADS_)            \
     GYMRS_AQL_STEP(PREFIX_##_so, ENV_, (FLAGS_) | kFlagNtOut | kFlagNtStateLoads, THREADS_) \
     GYMRS_AQL_STEP(PREFIX_##_pl, ENV_, (FLAGS_), THREADS_)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t512, CartPoleT, kAS, 512)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_t256, CartPoleT, kAS, 256)
-// (CartPole with all three flags = Gym's CartPole-v1 with its 500-step cap: the launches of a limit-eliding engine that DO check the limit)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_lim_t512, CartPoleT, kAST, 512)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_cartpole_lim_t256, CartPoleT, kAST, 256)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_mountain_car_t256, MountainCarT, kAS, 256)
-GYMRS_AQL_STEP_HINTS(gymrs_aql_pendulum_t256, PendulumT, kAST, 256)
+static_assert(GYMRS_AUTO_RESET == 1u && GYMRS_TRACK_STATS == 2u && GYMRS_TIME_LIMIT == 4u, "the f<N> of the kernel names is these three bits");
+#define GYMRS_AQL_STEP_FLAGSETS(ENV_NAME_, ENV_, THREADS_)                               \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f0_t##THREADS_, ENV_, 0u, THREADS_)     \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f1_t##THREADS_, ENV_, 1u, THREADS_)     \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f3_t##THREADS_, ENV_, 3u, THREADS_)     \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f4_t##THREADS_, ENV_, 4u, THREADS_)     \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f5_t##THREADS_, ENV_, 5u, THREADS_)     \
+    GYMRS_AQL_STEP_HINTS(gymrs_aql_##ENV_NAME_##_f7_t##THREADS_, ENV_, 7u, THREADS_)
+GYMRS_AQL_STEP_FLAGSETS(cartpole, CartPoleT, 512)
+GYMRS_AQL_STEP_FLAGSETS(cartpole, CartPoleT, 256)
+GYMRS_AQL_STEP_FLAGSETS(mountain_car, MountainCarT, 256)
+GYMRS_AQL_STEP_FLAGSETS(pendulum, PendulumT, 256)
 
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put

@@ -262,14 +262,14 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
     gymrs_aql.hip) for the engine's own AQL dispatcher: an ELF for amdgcn with the C-named kernels in it.  bench.py's
     roofline.kernel names the variant the engine's chain_hint_bits picks for a size."""
     blob = (ROOT / "gym-rs_amd" / "libgymrs_amd.so").read_bytes()
-    for name in (b"gymrs_aql_cartpole_t512_so", b"gymrs_aql_cartpole_t256_o", b"gymrs_aql_mountain_car_t256_so", b"gymrs_aql_pendulum_t256_o",
-                 b"gymrs_aql_pendulum_t256_nt", b"gymrs_aql_wait_flag", b"gymrs_aql_set_flag", b"gymrs_aql_selfcheck"):
+    for name in (b"gymrs_aql_cartpole_f3_t512_so", b"gymrs_aql_cartpole_f7_t256_o", b"gymrs_aql_mountain_car_f3_t256_so", b"gymrs_aql_pendulum_f7_t256_o",
+                 b"gymrs_aql_pendulum_f0_t256_nt", b"gymrs_aql_mountain_car_f5_t256_pl", b"gymrs_aql_wait_flag", b"gymrs_aql_set_flag", b"gymrs_aql_selfcheck"):
         assert blob.count(name + b".kd") >= 1, name
     import bench
 
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 20, "AQL chains: ...").startswith("gymrs_aql_cartpole_t512_so ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_cartpole_t512_o ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 24, "AQL chains: ...").startswith("gymrs_aql_cartpole_t512_nt ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 16, "AQL chains: ...").startswith("gymrs_aql_cartpole_t256_so ")
-    assert bench.kernel_name("pendulum", 4, 7, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_pendulum_t256_o ")
+    assert bench.kernel_name("cartpole", 4, 3, 1 << 20, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_so ")
+    assert bench.kernel_name("cartpole", 4, 3, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_o ")
+    assert bench.kernel_name("cartpole", 4, 3, 1 << 24, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_nt ")
+    assert bench.kernel_name("cartpole", 4, 3, 1 << 16, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t256_so ")
+    assert bench.kernel_name("pendulum", 4, 7, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_pendulum_f7_t256_o ")
     assert bench.kernel_name("mountain_car", 4, 3, 1 << 20, "HIP launches (...)") == "step_kernel<mountain_car, 4, flags=3>"

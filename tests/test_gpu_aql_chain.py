@@ -103,6 +103,47 @@ def test_chain_equals_hip_launches_and_the_twin(gymrs, twin, kind, n):
         e.close()
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("flags", [0, 1, 3, 4, 5, 7])
+def test_every_flag_set_has_its_chain(gymrs, twin, kind, flags):
+    """Chains are not a fast path for the benchmarked flag sets only: every flag set of the launch table (at 4 lanes per
+    work-item) has its kernels in the chain's code object.  A short episode cap, so that engines with GYMRS_TIME_LIMIT do
+    truncate; without GYMRS_AUTO_RESET finished lanes stay finished (CartPole's steps_beyond_terminated bookkeeping)."""
+    n, nbuf, steps = 20_003, 4, 61
+    p = gymrs.engine.default_params(kind)
+    p.max_episode_steps = 17
+    got = {}
+    for on in (True, False):
+        with aql(on):
+            eng = gymrs.BatchedEngine(kind, n, flags=flags, params=p, global_env_offset=77)
+            eng.reset(seed=4)
+            ring = ring_for(eng, kind, n, nbuf)
+            eng.step_many(ring.data_ptr(), ring.stride(0) * ring.element_size(), nbuf, steps)
+            stats = eng.stats() if flags & gymrs.TRACK_STATS else None
+            got[on] = (eng, eng.get_state(), eng.get_step_result(), eng.get_obs(), stats, ring)
+    x_on = extras(got[True][0])
+    assert x_on["aql"] == "on" and x_on["aql_launches"] == steps, x_on
+    assert extras(got[False][0])["aql_launches"] == 0
+    assert same(got[True][1], got[False][1]) and same(got[True][3], got[False][3])
+    for a, b in zip(got[True][2], got[False][2]):
+        assert same(a, b) if a.dtype == np.float32 else np.array_equal(a, b)
+    tw = TwinEngine(twin, kind, n, p, flags=flags, gid0=77)
+    tw.reset(4)
+    bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+    for t in range(steps):
+        tw.step(bufs[t % nbuf])
+    assert same(got[True][1], tw.get_state())
+    res = tw.get_result()
+    assert same(got[True][2][0], res[0]) and np.array_equal(got[True][2][1], res[1]) and np.array_equal(got[True][2][2], res[2])
+    if got[True][4] is not None:
+        if kind == 2:  # (Pendulum's returns are float sums taken per wavefront: the twin adds them in another order)
+            assert np.allclose(got[True][4], got[False][4], rtol=1e-5) and np.allclose(got[True][4], tw.stats(), rtol=1e-5)
+        else:
+            assert np.array_equal(got[True][4], got[False][4]) and np.array_equal(got[True][4], tw.stats())
+    for on in (True, False):
+        got[on][0].close()
+
+
 def test_chains_interleaved_with_hip_launches_statistics_and_copies(gymrs, twin):
     """chain -> gymrs_step (HIP) -> statistics -> chain -> set_state -> chain -> clone -> chain on both: every boundary between
     the two submission paths, at a size whose reset-log ring is folded inside chains and by the stand-alone kernel."""
@@ -150,7 +191,7 @@ def test_chains_interleaved_with_hip_launches_statistics_and_copies(gymrs, twin)
         eng.close()
 
 
-def test_short_calls_and_other_flag_sets_keep_to_hip_launches(gymrs):
+def test_short_calls_graphs_small_engines_and_other_launch_shapes_keep_to_hip_launches(gymrs):
     n = 5000
     with aql(True):
         with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS) as eng:
@@ -160,11 +201,12 @@ def test_short_calls_and_other_flag_sets_keep_to_hip_launches(gymrs):
             assert extras(eng)["aql_launches"] == 0
             eng.step_many(ring.data_ptr(), n, 4, 40, use_graph=True)   # graph replays are HIP's
             assert extras(eng)["aql_launches"] == 0
-        with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET) as eng:   # a flag set the stand-alone code object does not hold
+        with gymrs.BatchedEngine(0, 48, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS) as eng:   # a small engine's arrays are mapped host memory
             eng.reset(seed=1)
-            ring = ring_for(eng, 0, n, 4)
-            eng.step_many(ring.data_ptr(), n, 4, 40)
+            ring = ring_for(eng, 0, 48, 4)
+            eng.step_many(ring.data_ptr(), 48, 4, 40)
             assert extras(eng)["aql_launches"] == 0
+        # 8 lanes per work-item (a tuning knob): the chain's code object holds the 4-lane kernels only
         with gymrs.BatchedEngine(0, n, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS, lanes_per_thread=8) as eng:
             eng.reset(seed=1)
             ring = ring_for(eng, 0, n, 4)
