@@ -99,7 +99,12 @@ struct DeviceCtx {
     // bumped whenever a chain object of this device is created or destroyed: which hand-over suits an engine depends on where its
     // queues sit among the process's queues, so every engine looks again (aql_calibrate, ~3 ms) when the set of chains has changed
     std::atomic<uint32_t> epoch{0};
+    std::atomic<int> live{0}; // chain objects (= HSA queues) alive on this device
 };
+
+// Every chain object is a hardware queue of its own next to the HIP runtime's; a process that creates engines by the dozen must
+// not oversubscribe the device's queue slots with them.  Engines beyond this many keep to HIP launches (they say why).
+constexpr int kMaxChainsPerDevice = 8;
 
 constexpr int kMaxDevices = 64;
 DeviceCtx g_ctx[kMaxDevices];
@@ -434,6 +439,11 @@ AqlChain* aql_create(int hip_device, std::string* why)
             return nullptr;
         }
     }
+    if (c->live.fetch_add(1, std::memory_order_relaxed) >= kMaxChainsPerDevice) {
+        c->live.fetch_sub(1, std::memory_order_relaxed);
+        *why = "this process already drives " + std::to_string(kMaxChainsPerDevice) + " engines of this device through chains";
+        return nullptr;
+    }
     AqlChain* ch = new AqlChain();
     ch->ctx = c;
     ch->device = hip_device;
@@ -502,6 +512,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
     }
     if (!ok) {
         if (why->find("hand-over self-check") == std::string::npos) aql_destroy(ch);
+        else c->live.fetch_sub(1, std::memory_order_relaxed);
         return nullptr;
     }
     c->epoch.fetch_add(1, std::memory_order_relaxed);
@@ -511,7 +522,10 @@ AqlChain* aql_create(int hip_device, std::string* why)
 void aql_destroy(AqlChain* c)
 {
     if (!c) return;
-    if (c->ctx) c->ctx->epoch.fetch_add(1, std::memory_order_relaxed);
+    if (c->ctx) {
+        c->ctx->epoch.fetch_add(1, std::memory_order_relaxed);
+        c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
+    }
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);

@@ -298,6 +298,36 @@ def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
             eng.close()
 
 
+def test_engines_beyond_the_queue_budget_keep_to_hip_launches(gymrs):
+    """Every chain object is a hardware queue of its own: a process drives at most 8 engines per device through chains
+    (gymrs_aql.hip: kMaxChainsPerDevice); the others say so and step through HIP launches -- with the same results -- and an
+    engine created after some of the first were closed gets a chain again."""
+    n, nbuf, steps = 8192, 2, 16
+    flags = flags_of(gymrs, 0)
+    with aql(True):
+        engines, states = [], []
+        for k in range(11):
+            eng = gymrs.BatchedEngine(0, n, flags=flags)
+            eng.reset(seed=2)
+            ring = ring_for(eng, 0, n, nbuf)
+            eng.step_many(ring.data_ptr(), n, nbuf, steps)
+            engines.append(eng)
+            states.append(eng.get_state())
+        how = [extras(e)["aql"] for e in engines]
+        assert how[:8] == ["on"] * 8 and all("already drives" in h for h in how[8:]), how
+        assert [extras(e)["aql_launches"] for e in engines] == [steps] * 8 + [0] * 3
+        assert all(same(states[0], st) for st in states[1:])
+        for e in engines[:4]:
+            e.close()
+        with gymrs.BatchedEngine(0, n, flags=flags) as late:
+            late.reset(seed=2)
+            ring = ring_for(late, 0, n, nbuf)
+            late.step_many(ring.data_ptr(), n, nbuf, steps)
+            assert extras(late)["aql"] == "on" and same(late.get_state(), states[0])
+        for e in engines[4:]:
+            e.close()
+
+
 @pytest.mark.parametrize("kind,steps", [(2, 450), (0, 300), (1, 450)])
 def test_long_chains_forced_hints_reset_and_restore(gymrs, twin, kind, steps):
     """Chains that cross Pendulum's 200-step time limit twice (the host-computed truncate_all argument changes inside a chain), with
