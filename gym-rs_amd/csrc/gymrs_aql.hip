@@ -311,9 +311,16 @@ bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why)
     return true;
 }
 
+struct SelfCheckArgs { // gymrs_aql_selfcheck (gymrs_step_aql.hip)
+    float* x;
+    uint32_t n4, first;
+    uint32_t *xcc, *moved;
+};
+
 // The assumption the fence-free chain rests on, checked ON THIS DEVICE before the path is used: launches chained by the barrier
 // bit alone (agent acquire, NO release) see each other's stores -- with grids that are not multiples of the XCD count and with
-// one-workgroup launches in between (neither may change which XCD a workgroup index lands on).
+// one-workgroup launches in between (neither may change which XCD a workgroup index lands on) -- judged by the outcome (no lost
+// update) and by the hardware's own word: each workgroup index reads HW_REG_XCC_ID in every launch and must stay where it was.
 bool self_check(DeviceCtx* c, int device, std::string* why)
 {
     AqlChain ch;
@@ -321,17 +328,18 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
     ch.device = device;
     bool ok = false;
     float* x = nullptr;
-    uint32_t* flag = nullptr;
+    uint32_t *flag = nullptr, *xcc = nullptr; // xcc[0 .. kGroups): the XCC a workgroup index ran on first, [kGroups .. 2 kGroups): it moved
     hsa_signal_t done{};
-    constexpr uint32_t kLaunches = 96;
+    constexpr uint32_t kLaunches = 96, kGroups = 1022; // 1022 workgroups: not a multiple of 8, the last one partial
     do {
         if (!make_queue(c, &ch, why)) break;
-        const uint32_t n4 = 1021u * 256u + 77u; // 1022 workgroups: not a multiple of 8, the last one partial
-        if (hipMalloc(&x, (size_t)n4 * 16) != hipSuccess || hipMalloc(&flag, 64) != hipSuccess) {
+        const uint32_t n4 = (kGroups - 1u) * 256u + 77u;
+        if (hipMalloc(&x, (size_t)n4 * 16) != hipSuccess || hipMalloc(&flag, 64) != hipSuccess || hipMalloc(&xcc, 2 * kGroups * sizeof(uint32_t)) != hipSuccess) {
             *why = "self-check: hipMalloc failed";
             break;
         }
-        if (hipMemset(x, 0, (size_t)n4 * 16) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        if (hipMemset(x, 0, (size_t)n4 * 16) != hipSuccess || hipMemset(xcc, 0, 2 * kGroups * sizeof(uint32_t)) != hipSuccess ||
+            hipDeviceSynchronize() != hipSuccess) {
             *why = "self-check: hipMemset failed";
             break;
         }
@@ -339,10 +347,7 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = "self-check: hsa_signal_create failed";
             break;
         }
-        struct {
-            float* x;
-            uint32_t n4;
-        } args{x, n4};
+        SelfCheckArgs args{x, n4, 1u, xcc, xcc + kGroups};
         struct {
             uint32_t* flag;
             uint32_t seq;
@@ -352,7 +357,8 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
         bool staged_ok = true;
         for (uint32_t t = 0; t < kLaunches && staged_ok; ++t) {
             const bool last = t + 1 == kLaunches;
-            staged_ok = ch.stage(k, 1022u * 256u, 256, &args, sizeof(args), HSA_FENCE_SCOPE_AGENT, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
+            args.first = t == 0 ? 1u : 0u;
+            staged_ok = ch.stage(k, kGroups * 256u, 256, &args, sizeof(args), HSA_FENCE_SCOPE_AGENT, last ? HSA_FENCE_SCOPE_SYSTEM : HSA_FENCE_SCOPE_NONE,
                                  last ? done : hsa_signal_t{0}, why);
             if (staged_ok && !last && (t % 3) != 2) { // one-workgroup launches in between, as the ends of real chains are
                 fargs.seq = t;
@@ -378,6 +384,33 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = buf;
             break;
         }
+        std::vector<uint32_t> where(2 * kGroups);
+        if (hipMemcpy(where.data(), xcc, where.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            *why = "self-check: hipMemcpy failed";
+            break;
+        }
+        uint32_t moved = 0, unset = 0;
+        for (uint32_t g = 0; g < kGroups; ++g) {
+            moved += where[kGroups + g] != 0;
+            unset += where[g] == 0;
+        }
+        if (std::getenv("GYMRS_AQL_VERBOSE")) { // (developer knob: where the workgroup indices ran)
+            std::fprintf(stderr, "gymrs: AQL self-check, XCC of workgroup 0..23 in %u chained launches:", kLaunches);
+            for (uint32_t g = 0; g < 24; ++g) std::fprintf(stderr, " %u", where[g] - 1u);
+            uint32_t per_xcc[16] = {0};
+            for (uint32_t g = 0; g < kGroups; ++g) per_xcc[(where[g] - 1u) & 15u] += 1;
+            std::fprintf(stderr, "; workgroups per XCC:");
+            for (uint32_t k = 0; k < 16; ++k)
+                if (per_xcc[k]) std::fprintf(stderr, " %u:%u", k, per_xcc[k]);
+            std::fprintf(stderr, "; moved %u\n", moved);
+        }
+        if (moved || unset) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "self-check: %u of %u workgroup indices changed their XCD between the launches of a chain (%u never reported one)", moved,
+                          kGroups, unset);
+            *why = buf;
+            break;
+        }
         ok = true;
     } while (false);
     if (done.handle) hsa_signal_destroy(done);
@@ -385,6 +418,7 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
     if (ch.kernarg) hsa_amd_memory_pool_free(ch.kernarg);
     if (x) (void)hipFree(x);
     if (flag) (void)hipFree(flag);
+    if (xcc) (void)hipFree(xcc);
     return ok;
 }
 
@@ -637,10 +671,7 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream)
     constexpr uint32_t kN4 = 1u << 18; // 4 MB
     if (hipMalloc(&x, (size_t)kN4 * 16) != hipSuccess) return "asynchronous (not calibrated)";
     const AqlKernel k = c->ctx->kernels["gymrs_aql_selfcheck"];
-    struct {
-        float* x;
-        uint32_t n4;
-    } args{x, kN4};
+    SelfCheckArgs args{x, kN4, 0u, nullptr, nullptr};
     std::string why;
     auto time_chains = [&](bool sync) -> double {
         c->sync_mode = sync;

@@ -69,9 +69,20 @@ extern "C" __global__ __launch_bounds__(64) void gymrs_aql_set_flag(uint32_t* fl
 // ---- self-check of the assumption the fence-free chain rests on ---------------------------------------------------------
 // Every work-item adds 1 to its own 16 bytes; launched as a chain WITHOUT release fences, with one-workgroup launches in
 // between (they must not shift which XCD gets which workgroup) -- after K launches every word must read K.
-extern "C" __global__ __launch_bounds__(256) void gymrs_aql_selfcheck(float* x, uint32_t n4)
+// And the assumption itself, read from the hardware: every workgroup notes the XCC it runs on (HW_REG_XCC_ID) in the first
+// launch and compares in every later one; a workgroup index that moved to another XCD marks its slot of `moved`.
+extern "C" __global__ __launch_bounds__(256) void gymrs_aql_selfcheck(float* x, uint32_t n4, uint32_t first, uint32_t* xcc, uint32_t* moved)
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    if (xcc && threadIdx.x == 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        id = (id & 0xfu) + 1u; // (0 = never written)
+        if (first)
+            xcc[blockIdx.x] = id;
+        else if (xcc[blockIdx.x] != id)
+            moved[blockIdx.x] = 1u;
+    }
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n4) return;
     f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(x) + i);
