@@ -189,8 +189,12 @@ class HipBackend:
                              f"(one process per GPU)")
         torch.cuda.set_device(self.dev_index)
         self.device = torch.device("cuda", self.dev_index)
-        # RCCL refuses two ranks on one device: an oversubscribed TEST run meets over gloo instead
-        self.collective_backend = "gloo" if self.oversubscribed else "nccl"
+        # The control plane of a run (barrier, max over ranks, the agreement about which all-reduce to use) meets over gloo: it moves
+        # a few doubles on the host and is the path the multi-rank tests exercise (CPU ranks, and 2 / 8 ranks sharing the one GPU of a
+        # test box).  RCCL is used where the path has its one exchange, the statistics all-reduce, through the C ABI's own
+        # communicator (sharded.setup_stats_allreduce: watched first contact, gloo as the fall-back on ALL ranks).  GYMRS_BENCH_NCCL=1
+        # puts the control plane on torch.distributed's nccl (= RCCL) backend as well.
+        self.collective_backend = "nccl" if (os.environ.get("GYMRS_BENCH_NCCL") == "1" and not self.oversubscribed) else "gloo"
         self.gymrs = importlib.import_module("gym-rs_amd")
 
     def make_engine(self, kind, n, offset, flags, vec):
@@ -497,6 +501,7 @@ def run_rank(args, info, backend, make_collective=None):
                 "submission": submission,
                 "parallelism": f"lane-sharded x{info.world}, no data-path collective; 1 all-reduce of 4 f64 per run, after the clock",
                 "stats_allreduce": allreduce_path,
+                "control_plane": f"torch.distributed({backend.collective_backend}): barrier, max over ranks" if coll.active else "single process",
             },
             "timing": {
                 "repetitions": reps,

@@ -220,6 +220,10 @@ class Collective:
             import torch.distributed as dist
 
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if backend == "gloo" and os.environ.get("MASTER_ADDR", "") in ("127.0.0.1", "localhost", "::1"):
+                # a one-node rendezvous on the loopback address: gloo would otherwise look the container's hostname up first
+                # (it may not resolve, or only after a DNS timeout) before falling back to the loopback interface
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             import datetime
 
             # a rendezvous or collective whose peers never arrive ends the job with an error instead of hanging it
@@ -321,7 +325,7 @@ class ShardedRun:
                               timeout: Optional[float] = None) -> str:
         """Choose how the 4 statistics doubles are summed over ranks.  Preferred: the C ABI's own RCCL communicator
         (rank 0's ncclUniqueId travels through the torch.distributed store).  If the library's RCCL path cannot be
-        set up, torch.distributed's all-reduce (the same RCCL underneath) is used and the reason is kept.
+        set up, torch.distributed's all-reduce (the run's control-plane backend: gloo in bench.py) is used and the reason is kept.
 
         First contact is guarded (a rank stuck inside ncclCommInitRank used to hang the job): every native
         step runs under a watchdog of `timeout` seconds (GYMRS_COMM_TIMEOUT, default 90), and before the run's own engine
