@@ -106,6 +106,8 @@ def test_torchrun_form_with_one_rank_uses_the_native_rccl_path():
              "--master-port", "29617", "bench.py", "--gpus", "1", "--steps", "200", "--warmup", "20", "--cpu-seconds", "0", "--no-probe"], env=env)
     check_common(d, 1, 200, 20)
     assert d["config"]["stats_allreduce"].startswith("gymrs_allreduce_stats"), d["config"]
+    # barrier and max-over-ranks meet over gloo (what the multi-rank tests run); RCCL carries the statistics all-reduce
+    assert d["config"]["control_plane"].startswith("torch.distributed(gloo)"), d["config"]
 
 
 def test_plain_form_spawns_its_own_ranks():

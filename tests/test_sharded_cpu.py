@@ -244,6 +244,7 @@ def test_bench_rank_logic_gloo(tmp_path, twin, world):
     '''bench.run_rank itself with world_size 2 and 8 (BASELINE configs[4]'s shape: 8 shards, global env ids rank * n + i).'''
     out = run_workers(tmp_path, world)
     assert out["config"]["stats_allreduce"] == "torch.distributed(gloo)"  # the twin has no RCCL communicator
+    assert out["config"]["control_plane"].startswith("torch.distributed(gloo)")
     assert "cpu_baseline" not in out  # --cpu-seconds 0
     check_against_one_unsharded_twin(tmp_path, twin, out, world)
 
