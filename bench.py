@@ -320,8 +320,8 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
                 if res.returncode != 0 or not dbs:
                     return None, f"rocprofv3 --pmc {ctr} ({path_name}) failed (rc {res.returncode}): {res.stderr[-300:]}"
                 c = sqlite3.connect(str(dbs[0]))
-                like = f"gymrs_aql_{env_name}_t%" if path_name == "chain" else "%step_kernel%"
-                r = c.execute("select count(*), avg(value) from counters_collection where kernel_name like ? and counter_name = ?", (like, ctr)).fetchone()
+                glob = f"gymrs_aql_{env_name}_f[0-9]_t*" if path_name == "chain" else "*step_kernel*"  # (GLOB: `_` is a wildcard of LIKE)
+                r = c.execute("select count(*), avg(value) from counters_collection where kernel_name glob ? and counter_name = ?", (glob, ctr)).fetchone()
                 out[ctr] = {"launches": r[0], "avg_kb": r[1]}
             if not out["FETCH_SIZE"]["launches"] or not out["WRITE_SIZE"]["launches"]:
                 continue  # (that path did not run under the profiler: e.g. no chains on this box)

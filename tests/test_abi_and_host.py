@@ -273,3 +273,21 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
     assert bench.kernel_name("cartpole", 4, 3, 1 << 16, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t256_so ")
     assert bench.kernel_name("pendulum", 4, 7, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_pendulum_f7_t256_o ")
     assert bench.kernel_name("mountain_car", 4, 3, 1 << 20, "HIP launches (...)") == "step_kernel<mountain_car, 4, flags=3>"
+
+
+def test_committed_pmc_traffic_covers_both_submission_paths():
+    """profiles/pmc_traffic.json is what bench.py's roofline.traffic / traffic_chain_kernel quote.  When it belongs to the current
+    kernel sources it must hold, per env, the HIP-launched kernel's bytes AND the chain's own kernel's (a renamed kernel once made
+    the chain's record silently disappear from the file)."""
+    import json
+    from pathlib import Path
+
+    import bench
+
+    data = json.loads((Path(bench.ROOT) / "profiles" / "pmc_traffic.json").read_text())
+    if data.get("kernel_source_sha16") != bench.kernel_source_sha16():
+        pytest.skip("profiles/pmc_traffic.json belongs to other kernel sources (bench.py drops it as stale)")
+    for env in ("cartpole", "mountain_car", "pendulum"):
+        rec = data[env]
+        assert rec["bytes_per_launch"] > 0 and rec["chain"]["bytes_per_launch"] > 0, env
+        assert rec["raw"]["FETCH_SIZE"]["launches"] > 0 and rec["chain"]["raw"]["WRITE_SIZE"]["launches"] > 0, env
