@@ -262,8 +262,15 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
     gymrs_aql.hip) for the engine's own AQL dispatcher: an ELF for amdgcn with the C-named kernels in it.  bench.py's
     roofline.kernel names the variant the engine's chain_hint_bits picks for a size."""
     blob = (ROOT / "gym-rs_amd" / "libgymrs_amd.so").read_bytes()
-    for name in (b"gymrs_aql_cartpole_f3_t512_so", b"gymrs_aql_cartpole_f7_t256_o", b"gymrs_aql_mountain_car_f3_t256_so", b"gymrs_aql_pendulum_f7_t256_o",
-                 b"gymrs_aql_pendulum_f0_t256_nt", b"gymrs_aql_mountain_car_f5_t256_pl", b"gymrs_aql_wait_flag", b"gymrs_aql_set_flag", b"gymrs_aql_selfcheck"):
+    # every flag set of the 4-lane launch table x every hint variant (the names gymrs_engine.hip's aql_kernel_name asks for), + the chain's own three
+    names = [b"gymrs_aql_wait_flag", b"gymrs_aql_set_flag", b"gymrs_aql_selfcheck"]
+    for env, sizes in (("cartpole", (512, 256)), ("mountain_car", (256,)), ("pendulum", (256,))):
+        for threads in sizes:
+            for flags in (0, 1, 3, 4, 5, 7):
+                for hint in ("nt", "o", "so", "pl"):
+                    names.append(f"gymrs_aql_{env}_f{flags}_t{threads}_{hint}".encode())
+    assert len(names) == 99
+    for name in names:
         assert blob.count(name + b".kd") >= 1, name
     import bench
 
