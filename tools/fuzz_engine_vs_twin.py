@@ -2,10 +2,10 @@
 """tools/fuzz_engine_vs_twin.py -- developer tool: random walks through the engine's entry points, the CPU f32 twin replaying every one.
 
 Every case draws an env kind, a flag set, a lane count (log-uniform, ragged), an action ring and a sequence of operations --
-gymrs_step_many calls of random length (short ones are HIP launches, long ones chains through the engine's own AQL dispatcher),
-single gymrs_step launches, fused rollouts, statistics reads and clears, seeded resets, set_state, set_params with a new episode
-cap, clones that take over -- and after EVERY operation compares state bits, the step result arrays and the statistics with
-the twin (Pendulum's returns, float sums taken per wavefront, to 1e-5).  The point is the interplay of the host-side state
+gymrs_step_many calls of random length (short ones are HIP launches, long ones chains through the engine's own AQL dispatcher,
+some as replays of captured HIP graphs), single gymrs_step / gymrs_step_host launches, fused rollouts, statistics reads and
+clears, seeded resets, set_state, set_params with a new episode cap, clones that take over -- and after EVERY operation
+compares state bits, the step result arrays and the statistics with the twin (Pendulum's returns, float sums taken per wavefront, to 1e-5).  The point is the interplay of the host-side state
 machines (reset-log folds, the time-limit elision and its refreshes, chains that are closed and reopened in mid-call).
 
   python tools/fuzz_engine_vs_twin.py --cases 200 --seed 1        # ~1 minute on an MI355X
@@ -84,14 +84,22 @@ def main():
                 sys.exit(1)
 
         for _ in range(args.ops):
-            op = rng.choices(["many_long", "many_short", "step", "rollout", "stats_clear", "reset", "set_state", "set_params", "clone", "sync"],
-                             weights=[8, 3, 3, 2, 1, 1, 1, 2, 1, 1])[0]
-            if op in ("many_long", "many_short"):
-                k = rng.randint(8, 150) if op == "many_long" else rng.randint(1, 7)
-                log.append(f"step_many {k}")
-                eng.step_many(ring.data_ptr(), stride, nbuf, k)
+            op = rng.choices(["many_long", "many_short", "many_graph", "step", "step_host", "rollout", "stats_clear", "reset", "set_state", "set_params",
+                              "clone", "sync"], weights=[8, 3, 2, 3, 1, 2, 1, 1, 1, 2, 1, 1])[0]
+            if op in ("many_long", "many_short", "many_graph"):
+                graph = op == "many_graph"
+                if graph and kind == 2 and (flags & 4):
+                    continue  # (Pendulum's time limit is a host-computed kernel argument: gymrs_step_many refuses use_graph there)
+                k = rng.randint(8, 150) if op != "many_short" else rng.randint(1, 7)
+                log.append(f"step_many {k}" + (" use_graph" if graph else ""))
+                eng.step_many(ring.data_ptr(), stride, nbuf, k, use_graph=graph)
                 for t in range(k):
                     tw.step(bufs[t % nbuf])
+            elif op == "step_host":
+                b = rng.randrange(nbuf)
+                log.append(f"step_host buf {b}")
+                eng.step_host(bufs[b])
+                tw.step(bufs[b])
             elif op == "step":
                 b = rng.randrange(nbuf)
                 log.append(f"step buf {b}")
