@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--ops", type=int, default=14)
     ap.add_argument("--max-lanes", type=int, default=200_000)
+    ap.add_argument("--min-lanes", type=int, default=65, help="(> 64: smaller engines keep their arrays in mapped host memory)")
     ap.add_argument("--verbose", type=int, default=0)
     args = ap.parse_args()
     import torch
@@ -50,7 +51,7 @@ def main():
     for case in range(args.cases):
         kind = rng.choice([0, 0, 1, 2])
         flags = rng.choice([0, 1, 3, 3, 4, 5, 7, 7])
-        n = int(round(65 * (args.max_lanes / 65) ** rng.random()))
+        n = int(round(args.min_lanes * (args.max_lanes / args.min_lanes) ** rng.random()))
         nbuf = rng.randint(1, 9)
         gid0 = rng.choice([0, 12345, 1 << 33])
         p = gymrs.engine.default_params(kind)
