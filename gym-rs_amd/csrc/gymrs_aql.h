@@ -61,7 +61,12 @@ uint32_t aql_take_error(AqlChain* c);
 // the chains of this object use the synchronous hand-over (the host waits on both sides): see aql_create
 bool aql_is_synchronous(const AqlChain* c);
 // Decides, for this stream, between the asynchronous hand-over and the synchronous one (AqlChain::calibrated_for).  Cheap after
-// the first call per stream.  Returns a description when it decided anew (valid until the next call), NULL otherwise.
-const char* aql_calibrate(AqlChain* c, hipStream_t stream);
+// the first call per stream (it looks again only when another chain object has been CREATED on the device since).  Only a stream
+// the engine owns is timed (~3 ms of probe chains, hipStreamSynchronize on that stream); a caller-provided stream is never waited
+// for: its chains use the asynchronous hand-over.  Returns a description when it decided anew (valid until the next call), NULL otherwise.
+const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream);
+// What the device's self-check read from HW_REG_XCC_ID: nibble k = the XCC of the workgroup indices = k (mod 8).  Goes into every
+// chain launch's StepArgs::xcc_map; the kernels compare (step_kernel_body) and report through StepArgs::err_seen[1].
+uint32_t aql_xcc_map(const AqlChain* c);
 
 } // namespace gymrs

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(64) void aql_hip_wait_flag(const uint32_t* flag, ui
 constexpr uint32_t kQueuePackets = 4096;
 constexpr uint32_t kKernargSlots = 8 * kQueuePackets; // a slot is rewritten only after kQueuePackets later packets were CONSUMED
 constexpr uint32_t kFlushEvery = 64;
+constexpr uint32_t kCalibItems = 1u << 18; // 16-byte items of aql_calibrate's probe chains (4 MB)
 
 const char* hsa_err(hsa_status_t s)
 {
@@ -96,9 +97,14 @@ struct DeviceCtx {
     hsa_executable_t exe{};
     std::map<std::string, AqlKernel> kernels;
     int concurrent_handover = -1; // -1 not tried yet, 1 works, 0 kernels of two queues do not run side by side here (see aql_create)
-    // bumped whenever a chain object of this device is created or destroyed: which hand-over suits an engine depends on where its
-    // queues sit among the process's queues, so every engine looks again (aql_calibrate, ~3 ms) when the set of chains has changed
+    // bumped whenever a chain object of this device is CREATED: which hand-over suits an engine depends on where its queues sit
+    // among the process's queues, so an engine looks again (aql_calibrate, ~3 ms on its own stream) when a queue has appeared since
+    // it last looked.  A queue that goes away moves nobody (destroying an engine used to re-calibrate every other one).
     std::atomic<uint32_t> epoch{0};
+    // What the self-check read from the hardware: nibble k = the XCC workgroup indices = k (mod 8) ran on in every one of its chained
+    // launches.  Every production launch of a chain compares against it (StepArgs::xcc_map, step_kernel_body).
+    uint32_t xcc_map = 0;
+    float* calib_buf = nullptr; // scratch of aql_calibrate's probe chains (allocated once, at the self-check: no hipMalloc later)
     std::atomic<int> live{0}; // chain objects (= HSA queues) alive on this device
 };
 
@@ -339,7 +345,7 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             break;
         }
         if (hipMemset(x, 0, (size_t)n4 * 16) != hipSuccess || hipMemset(xcc, 0, 2 * kGroups * sizeof(uint32_t)) != hipSuccess ||
-            hipDeviceSynchronize() != hipSuccess) {
+            hipStreamSynchronize(nullptr) != hipSuccess) {
             *why = "self-check: hipMemset failed";
             break;
         }
@@ -411,6 +417,19 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = buf;
             break;
         }
+        // The production kernels re-check this in every launch against a table of 8 entries: the deal must repeat with period 8
+        // (round-robin over the XCDs; a partition with fewer XCDs repeats with a divisor of 8, which is fine too).
+        uint32_t aperiodic = 0, map = 0;
+        for (uint32_t g = 0; g < kGroups; ++g) aperiodic += where[g] != where[g & 7u];
+        if (aperiodic) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "self-check: the workgroup -> XCD deal does not repeat with period 8 (%u of %u indices differ from index mod 8)",
+                          aperiodic, kGroups);
+            *why = buf;
+            break;
+        }
+        for (uint32_t g = 0; g < 8; ++g) map |= ((where[g] - 1u) & 0xfu) << (4u * g);
+        c->xcc_map = map;
         ok = true;
     } while (false);
     if (done.handle) hsa_signal_destroy(done);
@@ -448,7 +467,11 @@ bool init_device(DeviceCtx* c, int device, std::string* why)
         return false;
     }
     if (!load_code(c, why)) return false;
-    return self_check(c, device, why);
+    if (!self_check(c, device, why)) return false;
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, (size_t)kCalibItems * 16), "hipMalloc (calibration scratch)");
+    c->calib_buf = static_cast<float*>(p);
+    return true;
 }
 
 } // namespace
@@ -506,7 +529,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
         }
         if (!ok) *why = "hipHostMalloc (error word) failed";
     }
-    if (ok) ok = hipDeviceSynchronize() == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(nullptr) == hipSuccess; // (the two hipMemset calls above; nothing else of the process is waited for)
     if (ok) ok = hsa_signal_create(1, 0, nullptr, &ch->done) == HSA_STATUS_SUCCESS;
     if (ok && c->concurrent_handover == 0) ch->sync_mode = ch->forced_sync = true;
     if (ok && std::getenv("GYMRS_AQL_SYNC")) { // (developer knob: synchronous hand-over everywhere)
@@ -556,10 +579,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
 void aql_destroy(AqlChain* c)
 {
     if (!c) return;
-    if (c->ctx) {
-        c->ctx->epoch.fetch_add(1, std::memory_order_relaxed);
-        c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
-    }
+    if (c->ctx) c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
@@ -653,7 +673,7 @@ bool aql_is_synchronous(const AqlChain* c) { return c && c->sync_mode; }
 // Does the asynchronous hand-over suit THIS pair of queues (the stream's and the chain's)?  Three short chains of the counting
 // kernel each way on the engine's own stream, host clock around call + synchronise; the synchronous hand-over is taken when a
 // chain behind the sleeping kernel is clearly slower (> 1.25 x).  ~3 ms, once per engine and stream.
-const char* aql_calibrate(AqlChain* c, hipStream_t stream)
+const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream)
 {
     if (c->forced_sync) return "synchronous (kernels of two queues do not run side by side here)";
     static thread_local char note[160];
@@ -667,9 +687,12 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream)
         c->sync_mode = v[0] == 's';
         return c->sync_mode ? "synchronous (forced)" : "asynchronous (forced)";
     }
-    float* x = nullptr;
-    constexpr uint32_t kN4 = 1u << 18; // 4 MB
-    if (hipMalloc(&x, (size_t)kN4 * 16) != hipSuccess) return "asynchronous (not calibrated)";
+    // A caller-provided stream is never waited for here (it may be blocked on work its owner has not submitted yet, or be under a
+    // capture): its chains use the asynchronous hand-over, whose only waits are the bounded ones on the device.
+    if (!own_stream) return "asynchronous (caller-provided stream: not calibrated)";
+    float* x = c->ctx->calib_buf;
+    if (!x) return "asynchronous (not calibrated)";
+    constexpr uint32_t kN4 = kCalibItems;
     const AqlKernel k = c->ctx->kernels["gymrs_aql_selfcheck"];
     SelfCheckArgs args{x, kN4, 0u, nullptr, nullptr};
     std::string why;
@@ -691,10 +714,18 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream)
     };
     const double t_async = time_chains(false), t_sync = time_chains(true);
     c->sync_mode = t_async > 1.25 * t_sync;
-    (void)hipFree(x);
     std::snprintf(note, sizeof(note), "%s (128-launch probe chains: %.0f us asynchronous, %.0f us synchronous)",
                   c->sync_mode ? "synchronous: a kernel on the stream's queue slows this chain's queue" : "asynchronous", t_async, t_sync);
     return note;
+}
+
+uint32_t aql_xcc_map(const AqlChain* c)
+{
+    uint32_t map = c->ctx->xcc_map;
+    // (test hook, tests/test_gpu_aql_chain.py: a table rotated by one entry makes every production launch find itself on the "wrong" XCD)
+    if (const char* v = std::getenv("GYMRS_AQL_TEST_WRONG_XCC"))
+        if (v[0] == '1') map = (map >> 4) | (map << 28);
+    return map;
 }
 
 uint32_t aql_take_error(AqlChain* c)

@@ -108,7 +108,7 @@ struct gymrs_engine {
     int nt_mode = 0; // 0 = automatic, 1 = always non-temporal, 2 = never
     unsigned long long* trace = nullptr; // developer instrumentation buffer (GYMRS_TRACE_TIMES builds)
     uint32_t* err = nullptr;
-    volatile uint32_t* err_seen = nullptr; // mapped host word: a kernel that saw an invalid action sets it (StepArgs::err_seen)
+    volatile uint32_t* err_seen = nullptr; // mapped host words (StepArgs::err_seen): [0] a kernel saw an invalid action, [1] a chain launch ran on another XCD than expected
     uint32_t* err_seen_dev = nullptr;
     double* stats_dev = nullptr;
     volatile double* stats_host = nullptr; // mapped host memory the read-out kernel writes the same four doubles into
@@ -265,6 +265,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.truncate_all = (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT) && e->tick + 1 - e->uniform_start >= e->max_steps) ? 1u : 0u;
     a.skip_trunc_store = (e->kind == GYMRS_PENDULUM && e->trunc_held == (int)a.truncate_all) ? 1u : 0u;
     a.trace = e->trace;
+    a.trace_wpb = (uint32_t)step_threads_of(e->kind, e->n, e->vec) / 64u;
     return a;
 }
 
@@ -630,6 +631,13 @@ gymrs_status gymrs_observation_space(gymrs_env_kind kind, const void* params, do
     return fail(GYMRS_EINVAL, "gymrs_observation_space: unknown env kind");
 }
 
+// GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
+static bool aql_enabled_by_env()
+{
+    const char* v = std::getenv("GYMRS_AQL");
+    return !(v && v[0] == '0');
+}
+
 // ---------------------------------------------------------------------------------------------
 gymrs_status gymrs_engine_destroy(gymrs_engine* e)
 {
@@ -840,11 +848,11 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     chk(dev_alloc(&e->err, 2));
     {
         void* host = nullptr;
-        if (st == GYMRS_OK && (hipHostMalloc(&host, sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        if (st == GYMRS_OK && (hipHostMalloc(&host, 2 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
                                hipHostGetDevicePointer(reinterpret_cast<void**>(&e->err_seen_dev), host, 0) != hipSuccess))
-            st = fail(GYMRS_EHIP, "hipHostMalloc (error flag)");
+            st = fail(GYMRS_EHIP, "hipHostMalloc (error flags)");
         if (host) {
-            *static_cast<uint32_t*>(host) = 0;
+            static_cast<uint32_t*>(host)[0] = static_cast<uint32_t*>(host)[1] = 0; // [0] invalid action seen, [1] a chain launch on the wrong XCD
             e->err_seen = static_cast<volatile uint32_t*>(host);
         }
     }
@@ -889,6 +897,17 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
         std::string msg = g_last_error;
         gymrs_engine_destroy(e);
         return fail(st, msg);
+    }
+    // The engine's own AQL dispatcher (chains of gymrs_step_many launches, gymrs_aql.h) is set up HERE, next to the other allocations,
+    // and the hand-over is timed on the engine's own, idle stream -- not inside the first gymrs_step_many, which is documented as
+    // asynchronous (queue creation, the device's self-check, hipMalloc and ~3 ms of probe chains used to happen there, on
+    // whatever stream the caller had set).  Without the path (GYMRS_AQL=0, a failed self-check, too many queues) the engine steps
+    // through HIP launches and says why in gymrs_env_json.
+    if (aql_enabled_by_env() && !e->pool_host) {
+        e->aql_tried = true;
+        e->aql = aql_create(e->device, &e->aql_why);
+        if (e->aql)
+            if (const char* how = aql_calibrate(e->aql, e->stream, true)) e->aql_handover = how;
     }
     *out = e;
     return GYMRS_OK;
@@ -1273,18 +1292,24 @@ static uint32_t chain_hint_bits(const gymrs_engine* e)
 
 static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
 {
-    if (n_steps < kAqlMinChain || e->vec != 4 || e->trace || e->pool_host) return false;
-    if (const char* v = std::getenv("GYMRS_AQL")) // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
-        if (v[0] == '0') return false;
+    if (n_steps < kAqlMinChain || e->vec != 4 || e->pool_host) return false;
+    if (!aql_enabled_by_env()) return false;
     if (!e->own_stream) { // a caller-provided stream may be under a capture: a chain cannot be captured
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(e->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
     }
-    if (!e->aql_tried) {
+    if (!e->aql_tried) { // (an engine created under GYMRS_AQL=0 and stepped without it: set up on first use)
         e->aql_tried = true;
         e->aql = aql_create(e->device, &e->aql_why);
     }
-    return e->aql != nullptr;
+    if (!e->aql) return false;
+    // which hand-over: decided at creation for the engine's own stream; again when another chain object has appeared on the device
+    // since, or the stream has changed (a caller-provided stream is never timed or waited for: asynchronous hand-over)
+    if (const char* how = aql_calibrate(e->aql, e->stream, e->own_stream)) e->aql_handover = how;
+    // the synchronous hand-over makes the HOST wait for the stream: never on a stream the engine does not own (it may be blocked on
+    // work its owner has not submitted yet) -- such an engine keeps to HIP launches where the asynchronous form is not available
+    if (!e->own_stream && aql_is_synchronous(e->aql)) return false;
+    return true;
 }
 
 extern "C++" {
@@ -1302,6 +1327,12 @@ static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const Ste
     ka.rest = a;
     ka.c = c;
     static_assert(sizeof(ka) <= kAqlKernargSlot, "kernel arguments larger than a ring slot");
+    // the block is filled by hand: it must be exactly what the code object's metadata says the kernel reads (no hidden arguments, no
+    // drifted layout -- a kernel that read beyond sizeof(ka) would find whatever the ring slot held a lap ago)
+    if (k.kernarg_bytes != sizeof(ka)) {
+        *err = "kernel-argument segment of the chain kernel is " + std::to_string(k.kernarg_bytes) + " bytes, the dispatcher fills " + std::to_string(sizeof(ka));
+        return false;
+    }
     return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err);
 }
 } // extern "C++"
@@ -1316,7 +1347,6 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     if (e->reset_log && e->log_pending != 0 && e->log_vec != e->vec) {
         if (gymrs_status st = fold_reset_log(e)) return st;
     }
-    if (const char* how = aql_calibrate(e->aql, e->stream)) e->aql_handover = how;
     if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched, no host state touched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
         aql_destroy(e->aql);
@@ -1329,6 +1359,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     if (const char* v = std::getenv("GYMRS_DEV_THREADS")) // (developer knob: 256 work-items per workgroup for CartPole chains)
         if (e->kind == GYMRS_CARTPOLE && std::atoi(v) == kBlock) threads = kBlock;
     uint32_t last_key = ~0u;
+    const uint32_t xcc_map = aql_xcc_map(e->aql);
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
         const std::string msg = g_last_error;
@@ -1344,6 +1375,8 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
         flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
+        a.xcc_map = xcc_map; // every wavefront of a chain launch checks where it runs (StepArgs::xcc_map)
+        a.xcc_check = 1u;
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
         if (!e->chain_open) { // (the host side of this step closed the chain: the step opens the next one)
             if (!aql_begin(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
@@ -1453,6 +1486,17 @@ gymrs_status gymrs_sync(gymrs_engine* e)
             return fail(GYMRS_EHIP, "a gymrs_step_many chain ran without waiting for the engine's stream: the stream did not reach the "
                                     "hand-over point within ~10 s (is it blocked on work that was never submitted?)");
         }
+    }
+    if (const uint32_t where = e->err_seen[1]) { // a wavefront of a chain launch found itself on another XCD than the self-check saw
+        e->err_seen[1] = 0;
+        aql_destroy(e->aql); // (the stream is idle: every chain ended with a wait on it)
+        e->aql = nullptr;
+        char buf[400];
+        std::snprintf(buf, sizeof(buf), "a gymrs_step_many chain ran workgroup %u on another XCD than the dispatcher's self-check saw for that index: the launches of a "
+                                        "chain carry no release fence, so the arrays may hold stale values since the last gymrs_sync; this engine now steps through HIP launches",
+                      where - 1u);
+        e->aql_why = "a chain launch ran on an unexpected XCD; HIP launches from then on";
+        return fail(GYMRS_EHIP, buf);
     }
     if (*e->err_seen == 0) return GYMRS_OK; // no kernel saw an invalid action: nothing to fetch
     uint32_t err[2] = {0, 0};

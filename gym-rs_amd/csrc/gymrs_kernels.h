@@ -44,8 +44,9 @@ struct StepArgs {
     uint32_t reset_log_row_words;
     uint32_t fold_step;            // this launch folds the ring (wave-uniform branch in step_block)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
-    uint32_t* err_seen; // mapped host word a wave that saw an invalid action sets to 1: gymrs_sync looks there first and
-                        // fetches err[] only then (no device-to-host copy per synchronisation)
+    uint32_t* err_seen; // mapped host words: [0] a wave that saw an invalid action sets it to 1: gymrs_sync looks there first and
+                        // fetches err[] only then (no device-to-host copy per synchronisation); [1] a wave of a CHAIN launch that found
+                        // itself on another XCD than the dispatcher's self-check saw for its workgroup index stores that index + 1
     uint64_t n;         // lanes in this engine
     uint64_t n_fast;    // n, or 0 when the action buffer is not aligned for the vector load (step_kernel)
     uint64_t gid0;      // global id of lane 0
@@ -56,6 +57,14 @@ struct StepArgs {
     uint32_t truncate_all; // envs that never terminate (Pendulum): this step hits the time limit for every lane
     uint32_t skip_trunc_store; // same envs: the `truncated` array already holds this step's (uniform) value
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
+    // Launches of a chain (gymrs_aql.h) carry no release fence between them, which is only right while tile i is stepped on the SAME
+    // XCD (= the same L2) in every launch.  xcc_check != 0: every wavefront compares the XCC it runs on (HW_REG_XCC_ID) with
+    // nibble (blockIdx.x & 7) of xcc_map -- what the dispatcher's self-check saw for that workgroup index on this device -- and
+    // reports a mismatch through err_seen[1].  HIP launches (a release fence each) pass 0.
+    uint32_t xcc_map;
+    uint32_t xcc_check;
+    uint32_t trace_wpb; // wavefronts per workgroup of this launch (the stamps' index; blockDim would be a hidden kernel argument, which
+                        // the engine's own dispatcher does not supply)
 };
 
 // The kernel-argument segment of step_kernel as the host sees it (the engine's own AQL dispatcher, gymrs_aql.h, fills it by

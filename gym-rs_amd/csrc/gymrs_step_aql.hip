@@ -85,7 +85,9 @@ extern "C" __global__ __launch_bounds__(256) void gymrs_aql_selfcheck(float* x, 
     }
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n4) return;
-    f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(x) + i);
+    // plain accesses, like the state arrays of the real chains: the lines stay dirty in this XCD's L2 until the next launch reads
+    // them there (streamed lines would leave the L2 early -- an easier case than the one the chains rest on)
+    f4 v = reinterpret_cast<const f4*>(x)[i];
     v += 1.0f;
-    __builtin_nontemporal_store(v, reinterpret_cast<f4*>(x) + i);
+    reinterpret_cast<f4*>(x)[i] = v;
 }

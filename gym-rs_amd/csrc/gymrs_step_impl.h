@@ -177,6 +177,15 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
         step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
+    // A launch of a chain: no release fence separates it from the next one, so this tile's lines must be found in THIS XCD's L2 by the
+    // next launch's workgroup of the same index (gymrs_aql.h).  The premise is checked where it matters, in every production launch,
+    // after the stores have been issued: a handful of scalar instructions per wavefront (kernel argument, blockIdx, one s_getreg).
+    if (rest.xcc_check != 0) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        const uint32_t want = (rest.xcc_map >> ((blockIdx.x & 7u) * 4u)) & 0xfu;
+        if ((id & 0xfu) != want && (threadIdx.x & 63u) == 0) rest.err_seen[1] = blockIdx.x + 1u;
+    }
 }
 
 #ifndef GYMRS_EXP_WAVES // (developer builds: the occupancy the register allocator aims for)

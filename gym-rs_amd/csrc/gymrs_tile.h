@@ -14,7 +14,7 @@ namespace gymrs {
 #define GYMRS_STAMP(slot_)                                                                                   \
     do {                                                                                                     \
         if (a.trace && (threadIdx.x & 63u) == 0)                                                             \
-            a.trace[((size_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
+            a.trace[((size_t)blockIdx.x * a.trace_wpb + (threadIdx.x >> 6)) * 8 + (slot_)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define GYMRS_STAMP(slot_) do { } while (0)
@@ -82,7 +82,8 @@ __device__ __forceinline__ Vec<T, V> load_vec(const T* __restrict__ p, uint64_t 
     return r;
 }
 
-template <class T, int V, bool NT>
+// POL: 0 plain, 1 non-temporal, 2 (developer builds, GYMRS_EXP_SC1) written through at agent scope (`sc1`)
+template <class T, int V, int POL>
 __device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint64_t n, bool full, const Vec<T, V>& r)
 {
     typedef T vt __attribute__((ext_vector_type(V)));
@@ -90,7 +91,15 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint
         vt x;
 #pragma unroll
         for (int k = 0; k < V; ++k) x[k] = r.v[k];
-        if (NT)
+        if constexpr (POL == 2) {
+            static_assert(sizeof(vt) == 4 || sizeof(vt) == 16, "sc1 stores: 4 lanes per work-item only");
+            if constexpr (sizeof(vt) == 16) {
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(reinterpret_cast<vt*>(p + base)), "v"(__builtin_bit_cast(u4, x)) : "memory");
+            }
+            else
+                asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 1" ::"v"(reinterpret_cast<vt*>(p + base)), "v"(__builtin_bit_cast(uint32_t, x)) : "memory");
+        } else if constexpr (POL == 1)
             __builtin_nontemporal_store(x, reinterpret_cast<vt*>(p + base));
         else
             *reinterpret_cast<vt*>(p + base) = x;
@@ -228,6 +237,13 @@ struct TileRegs {
                           NT_O = (GYMRS_EXP_HINTS & 8) != 0;
 #else
     static constexpr bool NT_SL = NT || (FLAGS & kFlagNtStateLoads) != 0, NT_SS = NT, NT_A = NT, NT_O = NT || (FLAGS & kFlagNtOut) != 0;
+#endif
+    // Store policies (store_vec): 0 plain, 1 non-temporal, 2 written through (`sc1`; developer builds: GYMRS_EXP_SC1 bit 1 = state
+    // stores, bit 3 = reward / done / truncated / obs stores -- profiles/r04_visible_step_probe.log says why no product launch uses it)
+#ifdef GYMRS_EXP_SC1
+    static constexpr int POL_SS = (VEC == 4 && (GYMRS_EXP_SC1 & 2)) ? 2 : (NT_SS ? 1 : 0), POL_O = (VEC == 4 && (GYMRS_EXP_SC1 & 8)) ? 2 : (NT_O ? 1 : 0);
+#else
+    static constexpr int POL_SS = NT_SS ? 1 : 0, POL_O = NT_O ? 1 : 0;
 #endif
     // Episode bookkeeping of the per-step kernel goes through the reset log (StepArgs::reset_log) when nothing in the
     // step needs ep_start itself: statistics on, no time limit, constant reward (return = +-length).
@@ -522,14 +538,14 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
     using R = TileRegs<Env, VEC, FLAGS>;
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
 #pragma unroll
-    for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::NT_SS>(a.s[j], base, a.n, FULL, d.st[j]);
-    if (!skip_reward) store_vec<float, kVec, R::NT_O>(a.reward, base, a.n, FULL, out.reward);
+    for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::POL_SS>(a.s[j], base, a.n, FULL, d.st[j]);
+    if (!skip_reward) store_vec<float, kVec, R::POL_O>(a.reward, base, a.n, FULL, out.reward);
     // An env that never terminates never changes `done` (reset() zeroed it), and its `truncated` flag is the same
     // for every lane: neither is rewritten while it already holds the right value (2 of Pendulum's 34 real bytes).
-    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::NT_O>(a.done, base, a.n, FULL, out.done);
-    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::NT_O>(a.truncated, base, a.n, FULL, out.trunc);
-    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::NT_SS>(a.beyond, base, a.n, FULL, d.beyond);
-    if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, false>(a.ep_start, base, a.n, FULL, d.ep_start);
+    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::POL_O>(a.done, base, a.n, FULL, out.done);
+    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::POL_O>(a.truncated, base, a.n, FULL, out.trunc);
+    if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::POL_SS>(a.beyond, base, a.n, FULL, d.beyond);
+    if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, 0>(a.ep_start, base, a.n, FULL, d.ep_start);
     if (Env::kHasObsExtra) {
         Vec<float, kVec> oc, os;
         bool med = true;
@@ -542,8 +558,8 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
 #pragma unroll
             for (int k = 0; k < kVec; ++k) sincosf_(d.st[0].v[k], &os.v[k], &oc.v[k]);
         }
-        store_vec<float, kVec, R::NT_O>(a.obs_cos, base, a.n, FULL, oc);
-        store_vec<float, kVec, R::NT_O>(a.obs_sin, base, a.n, FULL, os);
+        store_vec<float, kVec, R::POL_O>(a.obs_cos, base, a.n, FULL, oc);
+        store_vec<float, kVec, R::POL_O>(a.obs_sin, base, a.n, FULL, os);
     }
     GYMRS_STAMP(5); // stores issued
 #ifdef GYMRS_TRACE_TIMES

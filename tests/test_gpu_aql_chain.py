@@ -229,10 +229,8 @@ def test_invalid_action_inside_a_chain_is_reported(gymrs):
             assert extras(eng)["aql_launches"] == 16
 
 
-def test_full_size_chain_is_bit_identical_and_faster(gymrs):
-    """2^20 lanes (BASELINE configs[1]): 1000-step chains against 1000 HIP launches -- same bits, same statistics; and the
-    reason the path exists: the chain is faster (the HIP runtime's per-launch release fence costs this kernel > 1 us)."""
-    n, nbuf, steps = 1 << 20, 32, 1000
+def _full_size_both_ways(gymrs, steps, repetitions):
+    n, nbuf = 1 << 20, 32
     flags = flags_of(gymrs, 0)
     out = {}
     for on in (True, False):
@@ -244,19 +242,70 @@ def test_full_size_chain_is_bit_identical_and_faster(gymrs):
             eng.sync()
             stream = torch.cuda.ExternalStream(eng.stream, device=torch.device("cuda", 0))
             times = []
-            for _ in range(5):
+            for _ in range(repetitions):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
                 eng.step_many(ring.data_ptr(), n, nbuf, steps)
                 e1.record(stream)
                 eng.sync()
                 times.append(e0.elapsed_time(e1) * 1e3 / steps)
-            out[on] = (eng.get_state(), eng.stats(), sorted(times)[2], extras(eng))
+            out[on] = (eng.get_state(), eng.stats(), sorted(times)[len(times) // 2], extras(eng))
             eng.close()
+    return out
+
+
+def test_full_size_chain_is_bit_identical(gymrs):
+    """2^20 lanes (BASELINE configs[1]): 1000-step chains against 1000 HIP launches -- same bits, same statistics."""
+    steps = 1000
+    out = _full_size_both_ways(gymrs, steps, 2)
     assert same(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])
-    assert out[True][3]["aql_launches"] == 300 + 5 * steps and out[False][3]["aql_launches"] == 0
+    assert out[True][3]["aql_launches"] == 300 + 2 * steps and out[False][3]["aql_launches"] == 0
+
+
+@pytest.mark.perf
+def test_full_size_chain_is_faster(gymrs):
+    """The reason the path exists: the chain is faster (the HIP runtime's per-launch release fence costs this kernel > 1 us).  A timing
+    relation: runs after every correctness test (conftest.GPU_ORDER)."""
+    out = _full_size_both_ways(gymrs, 1000, 5)
     print(f"us per 2^20-lane step: AQL chain {out[True][2]:.3f}, HIP launches {out[False][2]:.3f}")
     assert out[True][2] < out[False][2]
+
+
+def test_a_chain_launch_on_an_unexpected_xcd_is_loud(gymrs, twin):
+    """The launches of a chain carry no release fence, which is only right while workgroup i runs on the same XCD in every launch.  The
+    dispatcher's self-check reads the deal from the hardware once per device; EVERY production launch of a chain then compares the
+    XCC it runs on (HW_REG_XCC_ID) with that table (step_kernel_body, StepArgs::xcc_map).  A table rotated by one entry (test hook
+    GYMRS_AQL_TEST_WRONG_XCC=1) stands in for a deal that changed under the engine: gymrs_sync must fail with GYMRS_EHIP, and the
+    engine must go on through HIP launches (VERDICT r3 "next" #3)."""
+    n, nbuf = 20_000, 4
+    flags = flags_of(gymrs, 0)
+    with aql(True):
+        with gymrs.BatchedEngine(0, n, flags=flags) as eng:
+            eng.reset(seed=4)
+            ring = ring_for(eng, 0, n, nbuf)
+            eng.step_many(ring.data_ptr(), n, nbuf, 16)
+            eng.sync()  # the true table: silent
+            assert extras(eng)["aql"] == "on" and extras(eng)["aql_launches"] == 16
+            os.environ["GYMRS_AQL_TEST_WRONG_XCC"] = "1"
+            try:
+                eng.step_many(ring.data_ptr(), n, nbuf, 16)
+                with pytest.raises(gymrs.GymrsError, match="another XCD") as info:
+                    eng.sync()
+                assert info.value.status == 2  # GYMRS_EHIP
+            finally:
+                os.environ.pop("GYMRS_AQL_TEST_WRONG_XCC", None)
+            x = extras(eng)
+            assert x["aql"] != "on" and "XCD" in x["aql"] and x["aql_launches"] == 32, x
+            eng.step_many(ring.data_ptr(), n, nbuf, 16)  # HIP launches from here on
+            eng.sync()
+            assert extras(eng)["aql_launches"] == 32
+            # (the deal had not really changed: the values are what the twin computes)
+            tw = TwinEngine(twin, 0, n, eng.params, flags=flags)
+            tw.reset(4)
+            bufs = [tw.fill_actions(5, b) for b in range(nbuf)]
+            for t in range(48):
+                tw.step(bufs[t % nbuf])
+            assert same(eng.get_state(), tw.get_state()) and np.array_equal(eng.stats(), tw.stats())
 
 
 def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
@@ -284,7 +333,6 @@ def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
                 eng.sync()
                 rates[k].append((time.perf_counter() - t0) * 1e6 / steps)
         best = [min(r[1:]) for r in rates]  # (the first round includes the calibration)
-        assert max(best) < 2.0 * min(best), rates
         for k, (eng, ring) in enumerate(engines):
             x = extras(eng)
             assert x["aql"] == "on" and x["aql_launches"] == 4 * steps and x["aql_handover"], x
@@ -296,6 +344,7 @@ def test_three_engines_in_one_process_alternate_chains(gymrs, twin):
                     tw.step(bufs[t % nbuf])
             assert same(eng.get_state(), tw.get_state()) and np.array_equal(eng.stats(), tw.stats())
             eng.close()
+        assert max(best) < 2.0 * min(best), rates  # (a coarse timing relation, checked after the bits: a factor of 2, not a rate)
 
 
 def test_engines_beyond_the_queue_budget_keep_to_hip_launches(gymrs):

@@ -1,0 +1,256 @@
+// tools/hbm_probe.hip -- developer experiment (VERDICT r3 "next" #4): what does a pure memory kernel get out of HBM on this box,
+// (a) as a plain 1 GiB -> 1 GiB copy (the guide measured 6.29 TB/s for a float4 copy; the in-library probe reads 5.97), and
+// (b) in the STEP's access pattern at 2^24 CartPole lanes: 4 state arrays read and written (dwordx4 per work-item), actions read
+// and done written as packed dwords, reward written -- 17 B read + 21 B written per lane, nine streams.
+// Knobs: grid shape (one tile per workgroup vs persistent grid-stride), tiles in flight per work-item, workgroup size,
+// non-temporal hints on loads / stores separately, the skew between the array bases.
+//   hipcc --offload-arch=gfx950 -O3 tools/hbm_probe.hip -o tools/hbm_probe && tools/hbm_probe [lanes_log2=24]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define HIP_OK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            std::fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            std::exit(1);                                                                  \
+        }                                                                                  \
+    } while (0)
+
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ u4 ld16(const u4* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void st16(u4* p, u4 v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <bool NT>
+__device__ __forceinline__ uint32_t ld4(const uint32_t* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void st4(uint32_t* p, uint32_t v)
+{
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+// ---- (a) plain copy: ITEMS 16-byte items per work-item per iteration, all loads before the first store; persistent when the grid is
+// smaller than the work (grid-stride over chunks of THREADS * ITEMS items)
+template <int THREADS, int ITEMS, bool NTL, bool NTS>
+__global__ __launch_bounds__(THREADS) void copy_kernel(const u4* __restrict__ src, u4* __restrict__ dst, uint64_t n16)
+{
+    const uint64_t chunk = (uint64_t)THREADS * ITEMS;
+    for (uint64_t c = blockIdx.x; c * chunk < n16; c += gridDim.x) {
+        const uint64_t first = c * chunk + threadIdx.x;
+        u4 v[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t i = first + (uint64_t)j * THREADS;
+            if (i < n16) v[j] = ld16<NTL>(src + i);
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const uint64_t i = first + (uint64_t)j * THREADS;
+            if (i < n16) st16<NTS>(dst + i, v[j]);
+        }
+    }
+}
+
+// ---- (b) the step's nine streams.  One "tile" of a work-item = 4 consecutive lanes: 4 x dwordx4 + 1 dword in, 5 x dwordx4 + 1 dword out.
+struct Streams {
+    const u4* s_in[4];
+    u4* s_out[4]; // = s_in (in place, as the step does) or separate buffers
+    const uint32_t* act;
+    u4* reward;
+    uint32_t* done;
+    uint64_t n4; // work-item tiles
+};
+
+// TILES tiles per work-item in flight (all their loads issued before the first store); persistent grid-stride over groups of tiles
+template <int THREADS, int TILES, bool NTL, bool NTS>
+__global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
+{
+    const uint64_t chunk = (uint64_t)THREADS * TILES;
+    for (uint64_t c = blockIdx.x; c * chunk < a.n4; c += gridDim.x) {
+        const uint64_t first = c * chunk + threadIdx.x;
+        u4 v[TILES][4];
+        uint32_t act[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const uint64_t i = first + (uint64_t)t * THREADS;
+            if (i < a.n4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[t][j] = ld16<NTL>(a.s_in[j] + i);
+                act[t] = ld4<NTL>(a.act + i);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const uint64_t i = first + (uint64_t)t * THREADS;
+            if (i < a.n4) {
+                v[t][0].x += 1u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st16<NTS>(a.s_out[j] + i, v[t][j]);
+                st16<NTS>(a.reward + i, v[t][3]);
+                st4<NTS>(a.done + i, act[t] ^ 0x01010101u);
+            }
+        }
+    }
+}
+
+static double time_launches(hipStream_t st, int launches, const auto& launch)
+{
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch();
+    HIP_OK(hipStreamSynchronize(st));
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIP_OK(hipEventRecord(e0, st));
+        for (int i = 0; i < launches; ++i) launch();
+        HIP_OK(hipEventRecord(e1, st));
+        HIP_OK(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / launches;
+        best = us < best ? us : best;
+    }
+    HIP_OK(hipEventDestroy(e0));
+    HIP_OK(hipEventDestroy(e1));
+    return best;
+}
+
+int main(int argc, char** argv)
+{
+    const int lanes_log2 = argc > 1 ? std::atoi(argv[1]) : 24;
+    hipStream_t st;
+    HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    // ---------------- (a) 1 GiB -> 1 GiB ----------------
+    {
+        const uint64_t bytes = 1ull << 30, n16 = bytes / 16;
+        u4 *src, *dst;
+        HIP_OK(hipMalloc(&src, bytes + 4096));
+        HIP_OK(hipMalloc(&dst, bytes + 4096));
+        HIP_OK(hipMemset(src, 1, bytes));
+        HIP_OK(hipMemset(dst, 0, bytes));
+        std::printf("# (a) copy 1 GiB read + 1 GiB written per launch; GB/s = 2 GiB / time\n");
+        std::printf("%-64s %10s %10s\n", "variant", "us", "GB/s");
+        auto report = [&](const char* label, double us) {
+            std::printf("%-64s %10.2f %10.0f\n", label, us, 2.0 * bytes / (us * 1e-6) / 1e9);
+            std::fflush(stdout);
+        };
+#define COPY_VARIANT(THREADS_, ITEMS_, NTL_, NTS_, GRID_, LABEL_)                                                                       \
+    {                                                                                                                                   \
+        const uint64_t full = (n16 + (uint64_t)THREADS_ * ITEMS_ - 1) / ((uint64_t)THREADS_ * ITEMS_);                                 \
+        const uint32_t grid = (uint32_t)((GRID_) == 0 ? full : (GRID_));                                                               \
+        char l[128];                                                                                                                    \
+        std::snprintf(l, sizeof(l), "%s: %d thr x %d items, nt loads %d stores %d, grid %u", LABEL_, THREADS_, ITEMS_, NTL_, NTS_, grid); \
+        report(l, time_launches(st, 10, [&] {                                                                                          \
+                   hipLaunchKernelGGL((copy_kernel<THREADS_, ITEMS_, NTL_, NTS_>), dim3(grid), dim3(THREADS_), 0, st, src, dst, n16);  \
+               }));                                                                                                                     \
+    }
+        COPY_VARIANT(256, 4, true, true, 0, "library probe shape (nt)")
+        COPY_VARIANT(256, 4, false, false, 0, "library probe shape (plain)")
+        COPY_VARIANT(256, 4, true, false, 0, "one chunk per WG")
+        COPY_VARIANT(256, 4, false, true, 0, "one chunk per WG")
+        COPY_VARIANT(256, 1, true, true, 0, "one chunk per WG")
+        COPY_VARIANT(256, 2, true, true, 0, "one chunk per WG")
+        COPY_VARIANT(256, 8, true, true, 0, "one chunk per WG")
+        COPY_VARIANT(512, 4, true, true, 0, "one chunk per WG")
+        COPY_VARIANT(1024, 4, true, true, 0, "one chunk per WG")
+        COPY_VARIANT(256, 4, true, true, 256 * 4, "persistent")
+        COPY_VARIANT(256, 4, true, true, 256 * 8, "persistent")
+        COPY_VARIANT(256, 4, true, true, 256 * 16, "persistent")
+        COPY_VARIANT(256, 8, true, true, 256 * 4, "persistent")
+        COPY_VARIANT(256, 8, true, true, 256 * 8, "persistent")
+        COPY_VARIANT(512, 4, true, true, 256 * 4, "persistent")
+        COPY_VARIANT(512, 8, true, true, 256 * 2, "persistent")
+        COPY_VARIANT(512, 8, true, true, 256 * 4, "persistent")
+        COPY_VARIANT(1024, 4, true, true, 256 * 2, "persistent")
+        COPY_VARIANT(256, 4, false, false, 256 * 8, "persistent (plain)")
+        COPY_VARIANT(256, 8, false, false, 256 * 8, "persistent (plain)")
+        COPY_VARIANT(256, 4, true, false, 256 * 8, "persistent")
+        COPY_VARIANT(256, 4, false, true, 256 * 8, "persistent")
+        // hipMemcpyAsync device-to-device for reference (the runtime's own blit kernel)
+        report("hipMemcpyAsync D2D", time_launches(st, 10, [&] { HIP_OK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st)); }));
+        HIP_OK(hipFree(src));
+        HIP_OK(hipFree(dst));
+    }
+    // ---------------- (b) the step's streams ----------------
+    {
+        const uint64_t n = 1ull << lanes_log2, n4 = n / 4;
+        const double alg = (double)n * 38.0;
+        std::printf("# (b) the step's nine streams at 2^%d lanes: %.1f MB per launch (17 B read + 21 B written per lane)\n", lanes_log2, alg / 1e6);
+        std::printf("%-84s %10s %10s\n", "variant", "us", "GB/s");
+        for (uint64_t skew : {0ull, 4352ull, 256ull * 37, 256ull * 1021, 4096ull * 3 + 256}) {
+            for (int inplace = 1; inplace >= 0; --inplace) {
+                if (!inplace && skew != 4352) continue;
+                // one pool, arrays carved with base k * skew apart from their power-of-two spacing (the engine: multiples of 4352 B)
+                const size_t arr = n * 4;
+                char* pool;
+                const size_t pool_bytes = arr * 9 + n * 2 + skew * 16 + (1 << 20);
+                HIP_OK(hipMalloc(&pool, pool_bytes));
+                HIP_OK(hipMemset(pool, 0, pool_bytes));
+                Streams a{};
+                size_t off = 0;
+                int k = 0;
+                auto carve = [&](size_t bytes) {
+                    char* p = pool + off + (size_t)(++k) * skew;
+                    off += (bytes + 4095) / 4096 * 4096;
+                    return p;
+                };
+                for (int j = 0; j < 4; ++j) a.s_in[j] = (const u4*)carve(arr);
+                for (int j = 0; j < 4; ++j) a.s_out[j] = inplace ? (u4*)a.s_in[j] : (u4*)carve(arr);
+                a.reward = (u4*)carve(arr);
+                a.act = (const uint32_t*)carve(n);
+                a.done = (uint32_t*)carve(n);
+                a.n4 = n4;
+                auto report = [&](const char* label, double us) {
+                    char l[160];
+                    std::snprintf(l, sizeof(l), "skew %6llu B %s | %s", (unsigned long long)skew, inplace ? "in place" : "out of place", label);
+                    std::printf("%-84s %10.2f %10.0f\n", l, us, alg / (us * 1e-6) / 1e9);
+                    std::fflush(stdout);
+                };
+#define STREAM_VARIANT(THREADS_, TILES_, NTL_, NTS_, GRID_)                                                                               \
+    {                                                                                                                                     \
+        const uint64_t full = (n4 + (uint64_t)THREADS_ * TILES_ - 1) / ((uint64_t)THREADS_ * TILES_);                                    \
+        const uint32_t grid = (uint32_t)((GRID_) == 0 ? full : (GRID_));                                                                 \
+        char l[96];                                                                                                                       \
+        std::snprintf(l, sizeof(l), "%d thr x %d tiles, nt loads %d stores %d, grid %u%s", THREADS_, TILES_, NTL_, NTS_, grid,           \
+                      (GRID_) == 0 ? "" : " (persistent)");                                                                               \
+        report(l, time_launches(st, 20, [&] {                                                                                            \
+                   hipLaunchKernelGGL((stream_kernel<THREADS_, TILES_, NTL_, NTS_>), dim3(grid), dim3(THREADS_), 0, st, a);              \
+               }));                                                                                                                       \
+    }
+                STREAM_VARIANT(512, 1, true, true, 0) // the step's launch shape today (CartPole: 512 work-items, every access hinted)
+                if (skew == 4352) {
+                    STREAM_VARIANT(256, 1, true, true, 0)
+                    STREAM_VARIANT(512, 1, false, false, 0)
+                    STREAM_VARIANT(512, 1, true, false, 0)
+                    STREAM_VARIANT(512, 1, false, true, 0)
+                    STREAM_VARIANT(512, 2, true, true, 0)
+                    STREAM_VARIANT(256, 2, true, true, 0)
+                    STREAM_VARIANT(512, 1, true, true, 256 * 2)
+                    STREAM_VARIANT(512, 1, true, true, 256 * 4)
+                    STREAM_VARIANT(256, 1, true, true, 256 * 4)
+                    STREAM_VARIANT(256, 1, true, true, 256 * 8)
+                    STREAM_VARIANT(512, 2, true, true, 256 * 2)
+                    STREAM_VARIANT(256, 2, true, true, 256 * 4)
+                    STREAM_VARIANT(256, 2, true, true, 256 * 8)
+                    STREAM_VARIANT(256, 4, true, true, 256 * 4)
+                } else {
+                    STREAM_VARIANT(256, 2, true, true, 256 * 4)
+                }
+                HIP_OK(hipFree(pool));
+            }
+        }
+    }
+    return 0;
+}

@@ -10,6 +10,9 @@ int main(int argc, char** argv)
 {
     const size_t n = 1u << 20;
     const uint32_t flags = argc > 1 ? atoi(argv[1]) : 3;
+    // steps of the traced call: >= 8 go through a chain (unless GYMRS_AQL=0); the stamps of the LAST step survive.  13 after the 200 warm-up
+    // steps ends on tick 212: not a folding launch (those are ticks = 7 mod 8)
+    const uint32_t traced = argc > 2 ? atoi(argv[2]) : 13;
     gymrs_engine* e;
     if (gymrs_engine_create(GYMRS_CARTPOLE, n, 0, 0, nullptr, flags, &e)) { printf("%s\n", gymrs_last_error()); return 1; }
     unsigned char* act; CK(hipMalloc(&act, n * 8));
@@ -20,7 +23,7 @@ int main(int argc, char** argv)
     const size_t waves = n / 256;
     unsigned long long* tr; CK(hipMalloc(&tr, waves * 8 * 8)); CK(hipMemset(tr, 0, waves * 8 * 8));
     gymrs_dev_set_trace(e, tr);
-    gymrs_step_many(e, act, n, 8, 3, 0);
+    gymrs_step_many(e, act, n, 8, traced, 0);
     gymrs_sync(e);
     std::vector<unsigned long long> h(waves * 8);
     CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
