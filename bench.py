@@ -6,7 +6,12 @@
         --master-port P bench.py --gpus N --steps K --warmup W      # or under an external launcher
 
 A "step" is ONE Env::step() of every lane of the workload = one launch of the step kernel over the
-rank's shard (auto-reset and statistics on).  Workload at N=1: BASELINE.json configs[1], CartPole-v1
+rank's shard (auto-reset and statistics on).  TWO call shapes are timed by the default run and both are printed (`paths`):
+  per_step_visible  the headline (`value`, `ms_per_step`, `roofline`): every step's arrays are RELEASED when its launch ends, so a
+                    reader between two steps -- the policy of examples/cartpole.rs:18-26, which looks at every step's ActionReward --
+                    sees them: K launches through HIP (what a gymrs_step loop enqueues; SURVEY H1 "keep the per-step round trip");
+  chain             reported separately: gymrs_step_many's chain through the engine's own dispatcher -- nothing is released until the
+                    chain ends, the state lives in the L2s in between (a multi-step-in-cache variant: SURVEY H1 "report separately").  Workload at N=1: BASELINE.json configs[1], CartPole-v1
 at 2^20 parallel envs, f32.  At N>1 every rank holds 2^20 lanes (weak scaling; configs[4] at N=8 is
 2^23 lanes) with global env ids rank*2^20+i and no data-path collective; the only collective of the
 path is one RCCL all-reduce of the 4 statistics doubles, taken AFTER the timed region (its cost is
@@ -50,6 +55,15 @@ ENVS = {
     "pendulum": (2, 1 << 22, 12, 25, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, auto-reset, 200-step time limit, random policy"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+L2_PEAK_GBPS = 34500.0  # aggregate of the eight 4 MiB L2s, same guide ("L2 (per XCD)": ~34.5 TB/s): what bounds a cache-resident chain
+# The two call shapes of the per-step API (docstring above): name -> (GYMRS_AQL for the calls, what it is)
+PATHS = {
+    "per_step_visible": ("0", "K launches through HIP, each with an agent-scope acquire and an end-of-kernel RELEASE (L2 write-back): every step's "
+                              "observations / rewards / flags are visible to whatever runs between two steps -- what a gymrs_step loop enqueues"),
+    "chain": ("1", "one gymrs_step_many chain through the engine's own HSA queue: agent-scope acquire on every launch, release only at the END of "
+                   "the chain -- nobody can read a step's arrays before the chain ends (reported separately from the headline)"),
+}
+HEADLINE_PATH = "per_step_visible"
 # VALU issue roofline of the fused rollout kernel: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
 MIN_REPETITION_SECONDS = 5e-3
@@ -64,8 +78,10 @@ SETTLE_SECONDS = 60e-3
 # (VERDICT r2 "next" #3): name -> (env, lanes, action buffers)
 EXTRA_CONFIGS = {
     "mountain_car_2p20": ("mountain_car", 1 << 20, 32),
-    "pendulum_2p22": ("pendulum", 1 << 22, 8),
+    "pendulum_2p22": ("pendulum", 1 << 22, 32),         # BASELINE configs[3] as the stand-alone `--env pendulum` run has it
+    "pendulum_2p22_8_action_buffers": ("pendulum", 1 << 22, 8),  # the same with a ring that fits the Infinity Cache (print both)
     "cartpole_2p24_dram_resident": ("cartpole", 1 << 24, 8),
+    "cartpole_2p25_hbm_streaming": ("cartpole", 1 << 25, 8),  # 1.27 GB per step: what a step READS (544 MiB) no longer fits the Infinity Cache either
 }
 
 
@@ -90,6 +106,74 @@ def kernel_name(env: str, vec: int, flags: int, n: int, submission):
     hint = "_nt" if per_step >= (340 << 20) else ("_so" if per_step <= (48 << 20) else "_o")
     threads = 512 if env == "cartpole" and n >= 512 * vec * 512 else 256
     return "gymrs_aql_%s_f%d_t%d%s (= step_kernel_body<%s, %d, flags=%d> in the chain's code object)" % (env, flags & 7, threads, hint, env, vec, flags)
+
+
+class submission:
+    """The call shape of the gymrs_step_many calls inside the block (PATHS): the library looks GYMRS_AQL up per call."""
+
+    def __init__(self, path):
+        self.value = PATHS[path][0] if path in PATHS else None
+
+    def __enter__(self):
+        self.before = os.environ.get("GYMRS_AQL")
+        if self.value is not None:
+            os.environ["GYMRS_AQL"] = self.value
+
+    def __exit__(self, *exc):
+        if self.value is None:
+            return
+        if self.before is None:
+            os.environ.pop("GYMRS_AQL", None)
+        else:
+            os.environ["GYMRS_AQL"] = self.before
+
+
+def load_free_running_traffic(config_name: str, path: str, sha: str):
+    """Fabric bytes per launch of FREE-RUNNING launches on this call shape: device-wide counter sampling around an undisturbed run
+    (tools/devcount: rocprofiler-sdk's device counting service; rocprofv3 --pmc counts per dispatch and serialises the queues), kept
+    in profiles/devcount_traffic.json together with the hash of the kernel sources it was taken with."""
+    try:
+        data = json.loads((ROOT / "profiles" / "devcount_traffic.json").read_text())
+    except Exception:
+        return None, "profiles/devcount_traffic.json missing"
+    if data.get("kernel_source_sha16") != sha:
+        return None, (f"profiles/devcount_traffic.json was collected with other kernel sources (sha {data.get('kernel_source_sha16')}, now {sha}): "
+                      f"dropped as stale; refresh with tools/devcount/collect.py")
+    rec = (data.get("configs", {}).get(config_name) or {}).get(path)
+    return rec, (None if rec else f"profiles/devcount_traffic.json has no entry for {config_name} / {path}")
+
+
+def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, kernel, sha):
+    """The roofline object of one call shape.  per_step_visible: the contract's HBM roofline (algorithmic bytes / launch time / 8 TB/s; SURVEY
+    H1b: at 2^20 lanes the arrays pass through the Infinity Cache, so this is a fraction of the HBM ROOFLINE, not a claim about DRAM
+    traffic -- `traffic` says what the fabric saw).  chain: the state lives in the L2s between launches, so the bound that applies is
+    the L2s' bandwidth, and no HBM fraction is printed (VERDICT r3 "next" #1b)."""
+    achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
+    peak = HBM_PEAK_GBPS if path != "chain" else L2_PEAK_GBPS
+    roof = {"bound": "hbm" if path != "chain" else "l2", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+            "traffic": None, "kernel": kernel, "bytes_per_env_step": bytes_per_step, "bytes_per_launch": n * bytes_per_step,
+            "launch_us": launch_us, "kernel_source_sha16": sha}
+    if path == "chain":
+        roof["bound_note"] = ("cache-resident: inside a chain the state is read out of the L2s (32 MiB, ~34.5 TB/s aggregate) and only write-backs and the "
+                              "streamed outputs cross the fabric, so the HBM roofline does not apply; the kernel is latency-bound (one generation of waves "
+                              "of ~3.4 us + a dependent launch), which is why `frac` of the L2s' bandwidth is low")
+    if traffic_rec:
+        roof["traffic"] = traffic_rec["bytes_per_launch"]
+        roof["traffic_read"] = traffic_rec.get("fetch_bytes")
+        roof["traffic_written"] = traffic_rec.get("write_bytes")
+        roof["traffic_source"] = "profiles/devcount_traffic.json: device-wide FETCH_SIZE / WRITE_SIZE around free-running launches of this call shape (same kernel sources)"
+        roof["traffic_over_algorithmic"] = traffic_rec["bytes_per_launch"] / (n * bytes_per_step)
+        roof["achieved_moved"] = traffic_rec["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
+        roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
+        if path != "chain":
+            roof["hbm_bound"] = roof["traffic_over_algorithmic"] >= 0.9
+            if not roof["hbm_bound"]:
+                roof["frac_note"] = ("the fabric sees %.2f x the algorithmic bytes: part of what a step reads is still in the L2s / the Infinity Cache from the step "
+                                     "before, so `frac` is a fraction of the HBM ROOFLINE (the contract's algorithmic bytes / time / 8 TB/s, SURVEY H1b), not HBM "
+                                     "utilisation; where every array streams from HBM see configs.cartpole_2p25_hbm_streaming" % roof["traffic_over_algorithmic"])
+    elif traffic_note:
+        roof["traffic_note"] = traffic_note
+    return roof
 
 
 def cpu_baseline(kind: int, target_seconds: float):
@@ -153,6 +237,8 @@ def parse_args(argv=None):
     ap.add_argument("--record", action="store_true",
                     help="with --rollout: gymrs_rollout_record, i.e. every step's observation/action/reward/done is kept")
     ap.add_argument("--graph", action="store_true", help="replay captured HIP graphs (pays for small batches only)")
+    ap.add_argument("--path", choices=["both", "per_step_visible", "chain"], default="both",
+                    help="call shape(s) of the per-step API to time (docstring); the headline is per_step_visible unless only chain is asked for")
     ap.add_argument("--torch-allreduce", action="store_true",
                     help="sum the statistics with torch.distributed instead of the C ABI's own RCCL communicator")
     ap.add_argument("--native-rccl", action="store_true", help="(default since round 2; kept for old command lines)")
@@ -378,7 +464,10 @@ def run_rank(args, info, backend, make_collective=None):
     eng.reset(seed=0)
     rec = backend.trajectory_buffers(eng, n, args.rollout, is_float) if (args.rollout and args.record) else None
 
+    steps_done = [0]  # steps since the last stats_clear (the run checks the all-reduced count against it)
+
     def run_steps(k):
+        steps_done[0] += k
         if args.rollout:
             done = 0
             while done < k:
@@ -392,98 +481,139 @@ def run_rank(args, info, backend, make_collective=None):
         else:
             eng.step_many(act_ptr, act_stride, nbuf, k, use_graph=args.graph)
 
-    # ---- warm-up, communicator set-up, calibration: all outside the timed repetitions ----
-    run_steps(args.warmup)
-    eng.sync()
-    # (an oversubscribed TEST run cannot use RCCL at all: it refuses two ranks on one device)
-    allreduce_path = run.setup_stats_allreduce(
-        prefer_native=not (args.torch_allreduce or getattr(backend, "oversubscribed", False)),
-        # first contact with RCCL happens on a throw-away engine with its own stream (sharded.setup_stats_allreduce says why)
-        make_probe_engine=(lambda off: backend.probe_engine(kind, off, flags)) if hasattr(backend, "probe_engine") else None)
-    if coll.active:
-        run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
-    backend.sync()
-    run_steps(args.steps)  # priming call: whatever the first full call sets up (the engine's AQL chain object, its self-check) is not stepping
-    backend.sync()
-    t_settle = time.perf_counter()
-    t0 = time.perf_counter()
-    run_steps(args.steps)  # first calibration pass: clocks may still be ramping up after a short warm-up
-    backend.sync()
-    first = time.perf_counter() - t0
-    pinned = os.environ.get("GYMRS_BENCH_PASSES")  # tests pin the amount of work to compare two runs' statistics
-    # ~2 ms more for the rate, and in any case until the device has been stepping for SETTLE_SECONDS (see there)
-    again = max(choose_passes(first, 2e-3), choose_passes(first, SETTLE_SECONDS) - 1)
-    again = 1 if pinned else min(again, 4096)
-    again = int(coll.max([again])[0])             # every rank steps the same number of times
-    t0 = time.perf_counter()
-    run_steps(args.steps * again)  # ONE call, like a timed repetition (a chain per call: many short calls would be another workload)
-    backend.sync()
-    per_pass = (time.perf_counter() - t0) / again
-    calibration_calls = [args.steps, args.steps, args.steps * again]
-    # (the estimate came from a SHORT call, which overstates the time per step: top the settle phase up if it fell short)
-    short = 0.0 if pinned else SETTLE_SECONDS - (time.perf_counter() - t_settle)
-    more = int(coll.max([math.ceil(short / max(per_pass, 1e-9)) if short > 0 else 0])[0])
-    if more > 0:
-        run_steps(args.steps * more)
-        backend.sync()
-        calibration_calls.append(args.steps * more)
-    passes = choose_passes(per_pass)
-    settle_ms = (time.perf_counter() - t_settle) * 1e3
-    if pinned:
-        passes = max(1, int(pinned))
-    passes = int(coll.max([passes])[0])  # every rank times the same work
-    eng.stats_clear()
+    # Which call shapes this run times (docstring): both unless --path names one; the fused rollout and graph replays are their own shape
+    per_step = not (args.rollout or args.graph)
+    paths = [HEADLINE_PATH, "chain"] if args.path == "both" else [args.path]
+    if not per_step:
+        paths = ["rollout" if args.rollout else "graph_replays"]
+    head = paths[0]
 
-    # ---- the timed region ----
+    def extras():
+        try:
+            return json.loads(eng.env_json(0))["gymrs"] if hasattr(eng, "env_json") else {}
+        except Exception:  # noqa: BLE001 -- diagnostics only
+            return {}
+
+    # ---- warm-up, communicator set-up, calibration: all outside the timed repetitions, on the headline's call shape ----
+    with submission(head):
+        run_steps(args.warmup)
+        eng.sync()
+        # (an oversubscribed TEST run cannot use RCCL at all: it refuses two ranks on one device)
+        allreduce_path = run.setup_stats_allreduce(
+            prefer_native=not (args.torch_allreduce or getattr(backend, "oversubscribed", False)),
+            # first contact with RCCL happens on a throw-away engine with its own stream (sharded.setup_stats_allreduce says why)
+            make_probe_engine=(lambda off: backend.probe_engine(kind, off, flags)) if hasattr(backend, "probe_engine") else None)
+        if coll.active:
+            run.allreduce_stats()  # RCCL builds its channels lazily on the first collective
+        backend.sync()
+        run_steps(args.steps)  # priming call
+        backend.sync()
+        t_settle = time.perf_counter()
+        t0 = time.perf_counter()
+        run_steps(args.steps)  # first calibration pass: clocks may still be ramping up after a short warm-up
+        backend.sync()
+        first = time.perf_counter() - t0
+        pinned = os.environ.get("GYMRS_BENCH_PASSES")  # tests pin the amount of work to compare two runs' statistics
+        # ~2 ms more for the rate, and in any case until the device has been stepping for SETTLE_SECONDS (see there)
+        again = max(choose_passes(first, 2e-3), choose_passes(first, SETTLE_SECONDS) - 1)
+        again = 1 if pinned else min(again, 4096)
+        again = int(coll.max([again])[0])             # every rank steps the same number of times
+        t0 = time.perf_counter()
+        run_steps(args.steps * again)  # ONE call, like a timed repetition
+        backend.sync()
+        per_pass = (time.perf_counter() - t0) / again
+        calibration_calls = [args.steps, args.steps, args.steps * again]
+        # (the estimate came from a SHORT call, which overstates the time per step: top the settle phase up if it fell short)
+        short = 0.0 if pinned else SETTLE_SECONDS - (time.perf_counter() - t_settle)
+        more = int(coll.max([math.ceil(short / max(per_pass, 1e-9)) if short > 0 else 0])[0])
+        if more > 0:
+            run_steps(args.steps * more)
+            backend.sync()
+            calibration_calls.append(args.steps * more)
+        passes = choose_passes(per_pass)
+        settle_ms = (time.perf_counter() - t_settle) * 1e3
+        if pinned:
+            passes = max(1, int(pinned))
+        passes = int(coll.max([passes])[0])  # every rank times the same work
+    eng.stats_clear()
+    steps_done[0] = 0
+
+    # ---- the timed region: R repetitions per call shape, the headline's first ----
     reps = max(1, args.repetitions)
-    # One call per repetition: P passes of K steps = one gymrs_step_many(P * K) -- one chain of launches through the engine's own
-    # AQL dispatcher (gymrs_aql.h), or P * K HIP launches where that path is not available.
-    # One more repetition up front, reported but not counted: stats_clear's kernels have just swept the episode bookkeeping
-    # through the caches, and the first call after them runs ~5 % slower than the rest.
-    walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps + 1)
-    lead_in_us = kernels[0] * 1e3 / (args.steps * passes)
-    walls, kernels = walls[1:], kernels[1:]
+    timed = {}
+    for path in paths:
+        with submission(path):
+            before = extras().get("aql_launches", 0)
+            if path != head:  # the other call shape: one untimed call of a repetition's length, so that its caches and clocks are its own
+                run_steps(args.steps * passes)
+                backend.sync()
+            # One call per repetition: P passes of K steps = one gymrs_step_many(P * K).  One more repetition up front, reported but not
+            # counted: whatever preceded the clock (stats_clear's kernels, the other call shape) has swept the caches.
+            walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps + 1)
+            ex = extras()
+            chained = ex.get("aql_launches", 0) - before
+            timed[path] = {"walls": walls[1:], "kernels": kernels[1:], "lead_in_us": kernels[0] * 1e3 / (args.steps * passes),
+                           "own_us": [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]],
+                           "chained_launches": chained, "last_launch": ex.get("last_launch"), "handover": ex.get("aql_handover"),
+                           "dispatcher": ex.get("aql")}
 
     # ---- read-out, after the clock: statistics all-reduce (the only collective of the path) ----
     backend.sync()
     t0 = time.perf_counter()
     total = run.allreduce_stats()
     stats_readout_us = (time.perf_counter() - t0) * 1e6
-    steps_per_lane = args.steps * passes * (reps + 1)  # (the lead-in repetition steps too)
-    run.check_total_steps(total, steps_per_lane)
-    # (kernels = max over ranks per repetition; every rank also reports its OWN event times)
-    own_us = [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]]
-    submission = None
-    if hasattr(eng, "env_json") and not args.rollout:
-        try:
-            ex = json.loads(eng.env_json(0))["gymrs"]
-            submission = ("AQL chains: the engine's own HSA queue, one chain per gymrs_step_many call, agent-scope acquire on every launch, "
-                          "release fence only at the end of the chain (gymrs_aql.h)") if ex.get("aql_launches", 0) > 0 else (
-                          "HIP launches (hipLaunchKernelGGL; AQL dispatcher: %s)" % ex.get("aql", "n/a"))
-        except Exception:  # noqa: BLE001 -- diagnostics only
-            submission = None
-    per_rank = coll.gather_to_root({"rank": info.rank, "device": getattr(backend, "dev_index", None), "submission": submission,
-                                    "global_env_offset": run.offset,
-                                    "launch_us": statistics.median(own_us), "launch_us_min": min(own_us), "launch_us_max": max(own_us),
-                                    "cpu_affinity": getattr(args, "cpu_affinity", None), "numa_node": getattr(args, "numa_node", None)})
+    run.check_total_steps(total, steps_done[0])
+
+    def submission_of(path, t):
+        if path not in PATHS:
+            return None
+        if path == "chain" and t["chained_launches"] <= 0:
+            return "HIP launches -- no chain ran (the engine's dispatcher: %s)" % t["dispatcher"]
+        if path == "chain":
+            return "AQL chains: the engine's own HSA queue, one chain per gymrs_step_many call, agent-scope acquire on every launch, release fence only at the end of the chain (gymrs_aql.h)"
+        return "HIP launches (hipLaunchKernelGGL): agent-scope acquire + release on every launch"
+
+    mine = {"rank": info.rank, "device": getattr(backend, "dev_index", None), "global_env_offset": run.offset,
+            "cpu_affinity": getattr(args, "cpu_affinity", None), "numa_node": getattr(args, "numa_node", None), "paths": {}}
+    for path, t in timed.items():
+        mine["paths"][path] = {"launch_us": statistics.median(t["own_us"]), "launch_us_min": min(t["own_us"]), "launch_us_max": max(t["own_us"]),
+                               "submission": submission_of(path, t), "handover": t["handover"] if path == "chain" else None}
+    hp = mine["paths"][head]  # the headline's figures also at the top of the rank record (what round 3's line carried)
+    mine.update({"launch_us": hp["launch_us"], "launch_us_min": hp["launch_us_min"], "launch_us_max": hp["launch_us_max"], "submission": hp["submission"]})
+    per_rank = coll.gather_to_root(mine)
     out = None
     if info.is_root:
-        wall = statistics.median(walls)
-        kernel_ms = statistics.median(kernels)
-        steps_timed = args.steps * passes
-        value = run.job_rate(steps_timed, wall)
-        launch_us = kernel_ms * 1e3 / steps_timed
-        achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
         sha = kernel_source_sha16()
+        steps_timed = args.steps * passes
+        config_name = {"cartpole": "cartpole_2p20", "mountain_car": "mountain_car_2p20", "pendulum": "pendulum_2p22"}[args.env] if (
+            args.n_envs in (0, n_default) and not args.vec) else None
+        path_out = {}
+        for path, t in timed.items():
+            wall = statistics.median(t["walls"])
+            kernel_ms = statistics.median(t["kernels"])
+            launch_us = kernel_ms * 1e3 / steps_timed
+            prec = {"what": PATHS[path][1] if path in PATHS else path, "value": run.job_rate(steps_timed, wall), "unit": "env-steps/s",
+                    "ms_per_step": wall * 1e3 / steps_timed, "launch_us": launch_us,
+                    "event_us_per_step": {"min": min(t["kernels"]) * 1e3 / steps_timed, "median": launch_us, "max": max(t["kernels"]) * 1e3 / steps_timed,
+                                          "spread": (max(t["kernels"]) - min(t["kernels"])) / kernel_ms},
+                    "wall_ms_per_repetition": [w * 1e3 for w in t["walls"]], "event_ms_per_repetition": t["kernels"],
+                    "lead_in_repetition_us_per_step": t["lead_in_us"], "submission": submission_of(path, t)}
+            if per_step:
+                trec, tnote = load_free_running_traffic(config_name, path, sha) if config_name else (None, "no committed traffic figure for this size / tuning")
+                prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha)
+                prec["roofline"]["how"] = ("HIP events on the engine's stream around ONE gymrs_step_many(P*K) call / (P*K), median of the repetitions: the back-to-back "
+                                           "launches with their gaps (for a chain also its hand-over from and back to the stream); rank 0's lanes")
+            path_out[path] = prec
+        hd = path_out[head]
         out = {
             "metric": "env-steps/sec (whole node), CartPole-v1 @ 2^20 envs per MI355X" if args.env == "cartpole"
                       else f"env-steps/sec (whole node), {args.env}",
-            "value": value,
+            "value": hd["value"],
             "unit": "env-steps/s",
             "n_gpus": info.world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall * 1e3 / steps_timed,
+            "ms_per_step": hd["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -498,7 +628,9 @@ def run_rank(args, info, backend, make_collective=None):
                 "lanes_per_work_item": args.vec or 4,
                 "action_buffers": nbuf,
                 "hip_graph": bool(args.graph),
-                "submission": submission,
+                "call_shape": head,
+                "call_shape_note": PATHS[head][1] if head in PATHS else head,
+                "submission": hd["submission"],
                 "parallelism": f"lane-sharded x{info.world}, no data-path collective; 1 all-reduce of 4 f64 per run, after the clock",
                 "stats_allreduce": allreduce_path,
                 "control_plane": f"torch.distributed({backend.collective_backend}): barrier, max over ranks" if coll.active else "single process",
@@ -509,14 +641,12 @@ def run_rank(args, info, backend, make_collective=None):
                 # untimed calls between the warm-up and the first repetition, in steps per call (priming, rate, settle)
                 "calibration_passes": sum(calibration_calls) // args.steps,
                 "calibration_calls": calibration_calls,
-                "lead_in_repetition_us_per_step": lead_in_us,  # the uncounted repetition right after stats_clear
+                "lead_in_repetition_us_per_step": hd["lead_in_repetition_us_per_step"],  # the uncounted repetition right after stats_clear
                 "settle_ms": settle_ms,  # untimed stepping right before the first repetition (calibration passes included)
                 "steps_per_repetition": steps_timed,
-                "wall_ms_per_repetition": [w * 1e3 for w in walls],
-                "event_ms_per_repetition": kernels,
-                "event_us_per_step": {"min": min(kernels) * 1e3 / steps_timed, "median": kernel_ms * 1e3 / steps_timed,
-                                      "max": max(kernels) * 1e3 / steps_timed,
-                                      "spread": (max(kernels) - min(kernels)) / kernel_ms},
+                "wall_ms_per_repetition": hd["wall_ms_per_repetition"],
+                "event_ms_per_repetition": hd["event_ms_per_repetition"],
+                "event_us_per_step": hd["event_us_per_step"],
                 "statistic": "median over repetitions of the max over ranks",
                 "stats_readout_us": stats_readout_us,
                 # CPUs this rank's launching thread and the HIP runtime's helpers were confined to (None = not pinned)
@@ -524,114 +654,90 @@ def run_rank(args, info, backend, make_collective=None):
                 "numa_node": getattr(args, "numa_node", None),  # the GPU's NUMA node when the block was taken from its local CPUs
             },
             "ranks": per_rank,
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
-                "kernel": kernel_name(args.env, args.vec or 4, flags, n, submission),
-                "bytes_per_env_step": bytes_per_step,
-                "bytes_per_launch": n * bytes_per_step,
-                "launch_us": launch_us,
-                "how": "HIP events on the engine's stream around ONE gymrs_step_many(P*K) call / (P*K), median of the repetitions: the "
-                       "back-to-back launches with their gaps, plus -- for an AQL chain -- its hand-over from and back to the stream; "
-                       "rank 0's lanes",
-                "kernel_source_sha16": sha,
-            },
             "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},
         }
+        if per_step:
+            out["roofline"] = hd["roofline"]
+            out["paths"] = path_out
+            if "chain" in path_out and head != "chain":
+                out["paths"]["chain"]["reported_separately"] = ("not the headline: inside a chain nobody can read a step's observation / reward / done before "
+                                                                "the chain ends (SURVEY H1: report multi-step variants separately)")
+        # N > 1: do the ranks agree on how they submit?  job rate = max over ranks, so ONE rank on another submission path or hand-over costs the
+        # whole job its difference, silently (VERDICT r3 "next" #8); and the rate the ranks' own launch times add up to, next to the measured one
+        agree = True
+        for path in timed:
+            subs = {(r["paths"][path]["submission"], (r["paths"][path]["handover"] or "").split(" (")[0]) for r in per_rank}
+            agree = agree and len(subs) == 1
+        out["ranks_agree"] = agree
+        if not agree:
+            out["ranks_agree_note"] = "ranks differ in submission path or hand-over: see ranks[*].paths"
+        out["expected_job_rate_from_rank_launch_times"] = sum(n / (r["launch_us"] * 1e-6) for r in per_rank)
         if run.allreduce_note:
             out["config"]["stats_allreduce_note"] = run.allreduce_note
         out["config"]["comm_watchdog"] = "a native RCCL call timed out and was abandoned" if run.abandoned else "not triggered"
         if getattr(backend, "oversubscribed", False):
             out["oversubscribed"] = "TEST RUN: ranks share GPUs and meet over gloo; value is not a benchmark result"
-        roof = out["roofline"]
-        if roof["frac"] > 1.0:
-            roof["frac_note"] = ("above 1: at this size one step's arrays (%.0f MB) stay in the L2s (32 MB) and the Infinity Cache (256 MB) -- inside a chain "
-                                 "not even the state leaves the L2s between launches -- so the algorithmic bytes move faster than HBM could deliver them; the "
-                                 "HBM-streaming figure of the same path is configs.cartpole_2p24_dram_resident" % (n * bytes_per_step / 1e6))
-        if not args.rollout:
-            # traffic: measured by this run (--pmc-traffic) or the committed figure if it belongs to these kernels
-            traffic, note = (None, None)
-            if args.pmc_traffic and info.world == 1 and backend.name == "hip":
-                rec_t, note = measure_pmc_traffic(args, args.env, sha)
-                traffic = rec_t["bytes_per_launch"] if rec_t else None
-                roof["traffic_source"] = "rocprofv3 --pmc passes run by this command"
-            else:
-                rec_t, note = load_pmc("pmc_traffic.json", args.env, sha)
-                if rec_t and (args.n_envs in (0, n_default)) and not args.vec:
-                    traffic = rec_t["bytes_per_launch"]
-                    roof["traffic_source"] = "profiles/pmc_traffic.json (same kernel sources)"
-            roof["traffic"] = traffic
-            if note:
-                roof["traffic_note"] = note
-            if traffic and submission and submission.startswith("AQL"):
-                roof["traffic_measured_on"] = ("the same kernel launched through HIP (every access hinted, a release fence inside every launch's "
-                                               "counter window): what the step moves when nothing stays in the L2s between launches")
-                chain_t = (rec_t or {}).get("chain")
-                if chain_t:
-                    # the chain's own kernel (PMC under rocprofv3's serialisation, synchronous hand-over): its state stores are still in the
-                    # L2s when it ends, so its window holds the reads and the streamed stores only
-                    roof["traffic_chain_kernel"] = {"bytes_per_launch": chain_t["bytes_per_launch"], "fetch_bytes": chain_t["fetch_bytes"],
-                                                    "write_bytes": chain_t["write_bytes"], "note": chain_t.get("note")}
-            if traffic:
-                # what is MOVED next to what is COUNTED: MountainCar elides its constant reward store, Pendulum's theta_dot
-                # observation column aliases the state column
-                roof["achieved_moved"] = traffic / (launch_us * 1e-6) / 1e9
-                roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
+        if per_step:
             if not args.no_probe and info.world == 1 and hasattr(backend, "copy_probe"):  # (a one-GPU diagnostic: no rank keeps the others waiting)
-                # the same box, the same process: what a plain copy gets (a) on HBM, (b) at this launch's footprint
-                nt = 1 if n * bytes_per_step <= (48 << 20) else 0
+                # the same box, the same process: what a plain copy gets (a) on HBM, (b) at this launch's footprint, submitted the way each
+                # call shape is submitted: HIP launches (a release fence each) for per_step_visible, launches of a chain for chain -- like for like
                 big = 1 << 30
-                # (streaming hint on and off: at 1 GiB + 1 GiB the hinted copy is the faster one; the guide's own float4 copy
-                # measured 6.29 TB/s -- the better of the two is what "a plain copy gets from HBM" means here)
                 both = [u for u in (backend.copy_probe(big, big, 20, 1), backend.copy_probe(big, big, 20, 0)) if u]
                 us_big = min(both) if both else None
-                us_same = backend.copy_probe(n * bytes_read // 16 * 16, n * bytes_written // 16 * 16, 500, nt)
-                if us_big and us_same:
-                    roof["peak_measured"] = {
-                        "hbm_copy_GBps": 2 * big / (us_big * 1e-6) / 1e9,
-                        "hbm_copy": "1 GiB read + 1 GiB written per launch (beyond the 256 MiB Infinity Cache), dwordx4 copy kernel, the "
-                                    "better of streaming-hinted and plain accesses",
-                        "same_footprint_copy_us": us_same,
-                        "same_footprint_copy_GBps": n * bytes_per_step / (us_same * 1e-6) / 1e9,
-                        "same_footprint_copy": f"{bytes_read} B read + {bytes_written} B written per lane, {n} lanes per launch, back-to-back "
-                                               "launches: the floor of a step launch of this size (launch cost included)",
-                    }
-                    roof["frac_of_measured_hbm_copy"] = achieved / roof["peak_measured"]["hbm_copy_GBps"]
-                    roof["frac_of_same_footprint_copy"] = us_same / launch_us
+                rd16, wr16 = n * bytes_read // 16 * 16, n * bytes_written // 16 * 16
+                for path, prec in path_out.items():
+                    base = 2 if path == "chain" else 0
+                    cands = [u for u in (backend.copy_probe(rd16, wr16, 500, base | 1), backend.copy_probe(rd16, wr16, 500, base)) if u]
+                    if not cands:
+                        continue
+                    us_same = min(cands)
+                    roof = prec["roofline"]
+                    roof["same_footprint_copy_us"] = us_same
+                    roof["same_footprint_copy"] = (f"{bytes_read} B read + {bytes_written} B written per lane, {n} lanes per launch, back-to-back launches submitted like "
+                                                   f"this call shape ({'launches of a chain' if path == 'chain' else 'HIP launches'}), the better of hinted / plain accesses: "
+                                                   "the floor of a step launch of this size")
+                    roof["frac_of_same_footprint_copy"] = us_same / roof["launch_us"]
+                    if us_big and path != "chain":
+                        roof["peak_measured"] = {"hbm_copy_GBps": 2 * big / (us_big * 1e-6) / 1e9,
+                                                 "hbm_copy": "1 GiB read + 1 GiB written per launch (beyond the 256 MiB Infinity Cache), dwordx4 copy kernel, one "
+                                                             "item per work-item, the better of streaming-hinted and plain accesses"}
+                        roof["frac_of_measured_hbm_copy"] = roof["achieved"] / roof["peak_measured"]["hbm_copy_GBps"]
         else:
             # The fused kernel touches HBM once per launch of R steps: it is bound by VALU issue, not by HBM.  Its roofline is
             # the instruction issue rate: SQ_INSTS_VALU per launch (PMC, profiles/pmc_valu.json) / launch time against
             # 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction.
-            n_launch = max(1, -(-args.steps // args.rollout)) * passes
-            launch_us_r = kernel_ms * 1e3 / n_launch
-            out["mode"] = "fused_rollout_recorded" if args.record else "fused_rollout"
-            out["config"]["steps_per_launch"] = args.rollout
-            out["config"]["workload"] = workload + f" -- fused rollout, {args.rollout} steps per launch (NOT the per-step headline)"
-            key = args.env + ("_recorded" if args.record else "")
-            rec_v, note = load_pmc("pmc_valu.json", key, sha)
-            roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instr/s", "frac": None,
-                    "traffic": None, "kernel": "rollout_kernel<%s, %d, flags=%d>" % (args.env, 4, flags), "launch_us": launch_us_r,
-                    "ns_per_lane_step": kernel_ms * 1e6 / steps_timed / n, "kernel_source_sha16": sha}
-            if rec_v and rec_v.get("steps_per_launch") == args.rollout and rec_v.get("lanes") == n:
-                per_launch = rec_v["SQ_INSTS_VALU_per_launch"]
-                roof["achieved"] = per_launch / (launch_us_r * 1e-6) / 1e9
-                roof["frac"] = roof["achieved"] / roof["peak"]
-                roof["valu_instr_per_wave_step"] = per_launch / (n / 256.0) / args.rollout
-                roof["how"] = ("SQ_INSTS_VALU per launch (profiles/pmc_valu.json, same kernel sources) / HIP-event launch time; peak = "
-                               "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (quarter-rate integer multiplies "
-                               "and LDS/branch issue slots make 1.0 unreachable)")
-            elif note:
-                roof["note"] = note
-            out["roofline"] = roof
+            kernel_ms = statistics.median(timed[head]["kernels"])
+            if args.rollout:
+                n_launch = max(1, -(-args.steps // args.rollout)) * passes
+                launch_us_r = kernel_ms * 1e3 / n_launch
+                out["mode"] = "fused_rollout_recorded" if args.record else "fused_rollout"
+                out["config"]["steps_per_launch"] = args.rollout
+                out["config"]["workload"] = workload + f" -- fused rollout, {args.rollout} steps per launch (NOT the per-step headline)"
+                key = args.env + ("_recorded" if args.record else "")
+                rec_v, note = load_pmc("pmc_valu.json", key, sha)
+                roof = {"bound": "valu", "achieved": None, "peak": VALU_PEAK_WAVE_INSTR_PER_S / 1e9, "unit": "G wave-instr/s", "frac": None,
+                        "traffic": None, "kernel": "rollout_kernel<%s, %d, flags=%d>" % (args.env, 4, flags), "launch_us": launch_us_r,
+                        "ns_per_lane_step": kernel_ms * 1e6 / steps_timed / n, "kernel_source_sha16": sha}
+                if rec_v and rec_v.get("steps_per_launch") == args.rollout and rec_v.get("lanes") == n:
+                    per_launch = rec_v["SQ_INSTS_VALU_per_launch"]
+                    roof["achieved"] = per_launch / (launch_us_r * 1e-6) / 1e9
+                    roof["frac"] = roof["achieved"] / roof["peak"]
+                    roof["valu_instr_per_wave_step"] = per_launch / (n / 256.0) / args.rollout
+                    roof["how"] = ("SQ_INSTS_VALU per launch (profiles/pmc_valu.json, same kernel sources) / HIP-event launch time; peak = "
+                                   "256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (quarter-rate integer multiplies "
+                                   "and LDS/branch issue slots make 1.0 unreachable)")
+                elif note:
+                    roof["note"] = note
+                out["roofline"] = roof
+            else:
+                out["mode"] = "hip_graph_replays"
+                launch_us = kernel_ms * 1e3 / steps_timed
+                out["roofline"] = roofline_of("per_step_visible", n, bytes_per_step, launch_us, None, "graph replays: no committed traffic figure", extras().get("last_launch"), sha)
     eng.close()
-    if (info.is_root and info.world == 1 and backend.name == "hip" and not args.rollout and not args.no_configs and args.env == "cartpole"
-            and not args.n_envs and not args.vec and not args.nt and not args.graph):
+    if (info.is_root and info.world == 1 and backend.name == "hip" and per_step and args.path == "both" and not args.no_configs and args.env == "cartpole"
+            and not args.n_envs and not args.vec and not args.nt):
         # the other BASELINE.json configs, driver-run: short legs after the headline (its engine is gone: one batch at a time)
-        out["configs"] = {name: measure_config(backend, gymrs, *spec, no_probe=args.no_probe) for name, spec in EXTRA_CONFIGS.items()}
+        out["configs"] = {name: measure_config(backend, gymrs, name, *spec, no_probe=args.no_probe) for name, spec in EXTRA_CONFIGS.items()}
     if info.is_root:
         gymrs.sharded.restore_cpus(getattr(args, "cpu_affinity_before", None))  # the CPU baseline may use every core
         # N > 1: a SHORT sample (the other ranks wait at the barrier below), so that a scaling line still carries the baseline
@@ -644,9 +750,12 @@ def run_rank(args, info, backend, make_collective=None):
     return out
 
 
-def measure_config(backend, gymrs, env_name, n, nbuf, no_probe=False, repetitions=5):
-    """One short leg for another BASELINE.json config on this GPU: same procedure as the headline (warm-up, settle, R repetitions
-    of >= 5 ms of back-to-back launches between HIP events on the engine's stream, median), reported as a sub-record."""
+def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=False, repetitions=5):
+    """One short leg for another BASELINE.json config on this GPU: same procedure as the headline (warm-up, settle, R repetitions of >= 5 ms
+    of back-to-back launches between HIP events on the engine's stream, median), BOTH call shapes, reported as a sub-record whose top-level
+    figures are the headline call shape's.  `roofline.frac` is what is MOVED wherever the fabric traffic of the leg is on file, next to
+    `frac_counted` (the algorithmic bytes the contract counts: MountainCar's elided constant reward store and Pendulum's aliased theta_dot
+    column are counted there and not moved; VERDICT r3 "next" #1e)."""
     kind, _, bytes_read, bytes_written, workload = ENVS[env_name]
     bytes_per_step = bytes_read + bytes_written
     flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if env_name == "pendulum" else 0)
@@ -655,6 +764,7 @@ def measure_config(backend, gymrs, env_name, n, nbuf, no_probe=False, repetition
     act_ptr, act_stride, _ring = backend.make_action_ring(eng, n, nbuf, env_name == "pendulum")
     eng.reset(seed=0)
     k = 64
+    sha = kernel_source_sha16()
 
     def timed(n_pass):
         m0 = backend.mark(stream)
@@ -664,31 +774,42 @@ def measure_config(backend, gymrs, env_name, n, nbuf, no_probe=False, repetition
         eng.sync()
         return backend.elapsed_ms(m0, m1)
 
-    timed(2)
-    per_pass = max(timed(4) / 4, 1e-3)                                   # ms per 64 steps
-    timed(max(1, int(SETTLE_SECONDS * 1e3 / per_pass)))                  # settle (untimed)
-    n_pass = max(1, int(math.ceil(MIN_REPETITION_SECONDS * 1e3 / per_pass)))
-    us = sorted(timed(n_pass) * 1e3 / (n_pass * k) for _ in range(repetitions))
-    launch_us = statistics.median(us)
+    rec = {"workload": (workload if n == ENVS[env_name][1] else f"{env_name} @ {n} envs") + f", ring of {nbuf} action buffers", "lanes": n, "action_buffers": nbuf,
+           "bytes_per_env_step": bytes_per_step, "repetitions": repetitions, "paths": {}}
+    for path in (HEADLINE_PATH, "chain"):
+        with submission(path):
+            before = json.loads(eng.env_json(0))["gymrs"].get("aql_launches", 0)
+            timed(2)
+            per_pass = max(timed(4) / 4, 1e-3)                                   # ms per 64 steps
+            timed(max(1, int(SETTLE_SECONDS * 1e3 / per_pass)))                  # settle (untimed)
+            n_pass = max(1, int(math.ceil(MIN_REPETITION_SECONDS * 1e3 / per_pass)))
+            us = sorted(timed(n_pass) * 1e3 / (n_pass * k) for _ in range(repetitions))
+            ex = json.loads(eng.env_json(0))["gymrs"]
+        launch_us = statistics.median(us)
+        trec, tnote = load_free_running_traffic(config_name, path, sha)
+        roof = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, ex.get("last_launch"), sha)
+        roof["frac_counted"], roof["achieved_counted"] = roof["frac"], roof["achieved"]
+        if trec and path != "chain":  # first-class = what is moved
+            roof["achieved"], roof["frac"] = roof["achieved_moved"], roof["frac_moved"]
+            roof["frac_is"] = "fabric bytes of a free-running launch / launch time / 8 TB/s (what is MOVED); frac_counted = the contract's algorithmic bytes"
+        prec = {"value": n / (launch_us * 1e-6), "unit": "env-steps/s", "launch_us": launch_us, "launch_us_min": us[0], "launch_us_max": us[-1],
+                "steps_per_repetition": n_pass * k, "roofline": roof,
+                "submission": ("chain" if ex.get("aql_launches", 0) > before else "HIP launches") if path == "chain" else "HIP launches"}
+        if not no_probe:
+            rd16, wr16 = n * bytes_read // 16 * 16, n * bytes_written // 16 * 16
+            base = 2 if path == "chain" else 0
+            cands = [u for u in (backend.copy_probe(rd16, wr16, max(20, int(2e3 / launch_us)), base | 1),
+                                 backend.copy_probe(rd16, wr16, max(20, int(2e3 / launch_us)), base)) if u]
+            if cands:
+                roof["same_footprint_copy_us"] = min(cands)
+                roof["frac_of_same_footprint_copy"] = min(cands) / launch_us
+        rec["paths"][path] = prec
     stats = eng.stats()
     eng.close()
     del _ring
-    achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
-    rec = {"workload": workload if n == ENVS[env_name][1] else f"{env_name} @ {n} envs (every array streams from HBM: 2^24 x 38 B = 640 MB per step)",
-           "lanes": n, "value": n / (launch_us * 1e-6), "unit": "env-steps/s", "launch_us": launch_us, "launch_us_min": us[0], "launch_us_max": us[-1],
-           "repetitions": repetitions, "steps_per_repetition": n_pass * k, "bytes_per_env_step": bytes_per_step,
-           "achieved_GBps": achieved, "frac": achieved / HBM_PEAK_GBPS, "episodes_finished": float(stats[2])}
-    if n == ENVS[env_name][1]:
-        rec_t, _ = load_pmc("pmc_traffic.json", env_name, kernel_source_sha16())
-        if rec_t:
-            rec["traffic"] = rec_t["bytes_per_launch"]
-            rec["frac_moved"] = rec_t["bytes_per_launch"] / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBPS
-    if not no_probe:
-        nt = 1 if (n * bytes_per_step <= (48 << 20) or n * bytes_per_step >= (340 << 20)) else 0
-        us_same = backend.copy_probe(n * bytes_read // 16 * 16, n * bytes_written // 16 * 16, max(20, int(2e3 / launch_us)), nt)
-        if us_same:
-            rec["same_footprint_copy_us"] = us_same
-            rec["frac_of_same_footprint_copy"] = us_same / launch_us
+    hd = rec["paths"][HEADLINE_PATH]
+    rec.update({"value": hd["value"], "unit": "env-steps/s", "launch_us": hd["launch_us"], "launch_us_min": hd["launch_us_min"], "launch_us_max": hd["launch_us_max"],
+                "roofline": hd["roofline"], "call_shape": HEADLINE_PATH, "episodes_finished": float(stats[2])})
     return rec
 
 
@@ -715,7 +836,12 @@ def main(argv=None) -> int:
     # -- taken from the CPUs local to the rank's GPU (its NUMA node) when the topology can be read
     args.cpu_affinity, args.cpu_affinity_before, args.numa_node = sharded.pin_rank_near_gpu(info.local_rank, n_local_ranks=info.world)
     backend = HipBackend(args, info)
-    out = run_rank(args, info, backend)
+    try:
+        out = run_rank(args, info, backend)
+    except TimeoutError as exc:  # a native collective that never completes (sharded.ShardedRun.allreduce_stats): its helper thread cannot be joined
+        sys.stderr.write(f"bench.py: {exc}\n")
+        sys.stderr.flush()
+        os._exit(3)
     if out is not None:
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     os.close(json_fd)

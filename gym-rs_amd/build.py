@@ -63,6 +63,14 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, PATH, /opt/rocm/bin/hipcc)")
 
 
+def _rocm_lib(hipcc: str) -> str:
+    """The ROCm library directory (libhsa-runtime64): $ROCM_PATH/lib, else next to the hipcc that is used, else /opt/rocm/lib."""
+    for root in (os.environ.get("ROCM_PATH"), str(Path(hipcc).resolve().parent.parent), "/opt/rocm"):
+        if root and (Path(root) / "lib").is_dir():
+            return str(Path(root) / "lib")
+    return "/opt/rocm/lib"
+
+
 def _run(cmd, cwd=None):
     print("+", " ".join(str(c) for c in cmd), flush=True)
     subprocess.run([str(c) for c in cmd], cwd=cwd, check=True)
@@ -89,14 +97,15 @@ def build_hip(force: bool = False, extra_flags=(), out: Path | None = None) -> P
         obj = objdir / (src.stem + ".o")
         embeds = src.stem == "gymrs_aql"  # .incbin of the code object: compiled after it
         if force or extra_flags or not _newer(obj, [src] + hdr_deps) or (embeds and hsaco_stale):
-            cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, f"-I{ROOT / 'include'}", f"-I{CSRC}", f'-DGYMRS_AQL_HSACO="{hsaco}"', "-c", src, "-o", obj]
+            # (gymrs_aql.hip embeds the code object with .incbin "gymrs_aql_kernels.hsaco": found through -I, so no path travels in a -D string)
+            cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, f"-I{ROOT / 'include'}", f"-I{CSRC}", *([f"-I{objdir}", f"-Wa,-I{objdir}"] if embeds else []), "-c", src, "-o", obj]
             (after if embeds else jobs).append(cmd)
     with ThreadPoolExecutor(max_workers=max(1, len(jobs))) as pool:
         list(pool.map(_run, jobs))
     for cmd in after:
         _run(cmd)
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *(objdir / (s.stem + ".o") for s in HIP_SOURCES), "-o", lib, "-ldl",
-          "-L/opt/rocm/lib", "-lhsa-runtime64"])
+          f"-L{_rocm_lib(hipcc)}", "-lhsa-runtime64"])
     return lib
 
 

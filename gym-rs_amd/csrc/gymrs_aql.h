@@ -65,8 +65,8 @@ bool aql_is_synchronous(const AqlChain* c);
 // the engine owns is timed (~3 ms of probe chains, hipStreamSynchronize on that stream); a caller-provided stream is never waited
 // for: its chains use the asynchronous hand-over.  Returns a description when it decided anew (valid until the next call), NULL otherwise.
 const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream);
-// What the device's self-check read from HW_REG_XCC_ID: nibble k = the XCC of the workgroup indices = k (mod 8).  Goes into every
-// chain launch's StepArgs::xcc_map; the kernels compare (step_kernel_body) and report through StepArgs::err_seen[1].
-uint32_t aql_xcc_map(const AqlChain* c);
+// [8] device words of this chain object for StepArgs::xcc_table: the first step launch of a chain records where its workgroups run,
+// the later launches of the chain compare (gymrs_kernels.h says why the table is per chain and not per queue or per device).
+uint32_t* aql_xcc_table(const AqlChain* c);
 
 } // namespace gymrs

@@ -16,13 +16,19 @@
 #include <vector>
 
 #if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__) || defined(__i386__)
 #include <immintrin.h>
-// The stand-alone code object of gymrs_step_aql.hip, built by build.py right before this file and embedded here.
+#define GYMRS_STORE_FENCE() _mm_sfence()
+#else
+#define GYMRS_STORE_FENCE() __atomic_thread_fence(__ATOMIC_SEQ_CST) // (a full barrier also drains the write-combining buffers)
+#endif
+// The stand-alone code object of gymrs_step_aql.hip, built by build.py right before this file (into the object directory, which is on
+// the assembler's include path) and embedded here.
 __asm__(".section .rodata\n"
         ".balign 4096\n"
         ".global gymrs_aql_blob_begin\n"
         "gymrs_aql_blob_begin:\n"
-        ".incbin \"" GYMRS_AQL_HSACO "\"\n"
+        ".incbin \"gymrs_aql_kernels.hsaco\"\n"
         ".global gymrs_aql_blob_end\n"
         "gymrs_aql_blob_end:\n"
         ".previous\n");
@@ -101,9 +107,6 @@ struct DeviceCtx {
     // among the process's queues, so an engine looks again (aql_calibrate, ~3 ms on its own stream) when a queue has appeared since
     // it last looked.  A queue that goes away moves nobody (destroying an engine used to re-calibrate every other one).
     std::atomic<uint32_t> epoch{0};
-    // What the self-check read from the hardware: nibble k = the XCC workgroup indices = k (mod 8) ran on in every one of its chained
-    // launches.  Every production launch of a chain compares against it (StepArgs::xcc_map, step_kernel_body).
-    uint32_t xcc_map = 0;
     float* calib_buf = nullptr; // scratch of aql_calibrate's probe chains (allocated once, at the self-check: no hipMalloc later)
     std::atomic<int> live{0}; // chain objects (= HSA queues) alive on this device
 };
@@ -188,6 +191,9 @@ public:
     uint32_t calibrated_epoch = 0;
     bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
+    // [8] device words the first step launch of every chain records the XCC of its workgroups 0 .. 7 in and the later launches of that
+    // chain compare against (StepArgs::xcc_table)
+    uint32_t* xcc_table = nullptr;
     unsigned long long wait_ticks = 10ull * 100000000ull; // bound of the chain's first packet (100 MHz ticks)
     std::atomic<int> queue_status{0};
     AqlKernel k_wait, k_set;
@@ -253,7 +259,7 @@ public:
     {
         if (staged.empty()) return;
 #if !defined(__HIP_DEVICE_COMPILE__)
-        _mm_sfence();
+        GYMRS_STORE_FENCE();
 #endif
         if (last_kernarg) (void)*static_cast<volatile uint32_t*>(last_kernarg);
         // One doorbell per packet (posted writes, cheap): rocprofiler's queue interception faults on a doorbell that publishes
@@ -278,7 +284,7 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe), "hsa_executable_create_alt");
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
-    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
+    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck", "gymrs_aql_copy_probe_pl", "gymrs_aql_copy_probe_nt"};
     for (const char* env_threads : {"cartpole_f%d_t512", "cartpole_f%d_t256", "mountain_car_f%d_t256", "pendulum_f%d_t256"}) // (gymrs_step_aql.hip)
         for (int flags : {0, 1, 3, 4, 5, 7})
             for (const char* hint : {"_nt", "_o", "_so", "_pl"}) {
@@ -428,8 +434,7 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = buf;
             break;
         }
-        for (uint32_t g = 0; g < 8; ++g) map |= ((where[g] - 1u) & 0xfu) << (4u * g);
-        c->xcc_map = map;
+        (void)map; // (the table itself is read per queue: probe_xcc_map)
         ok = true;
     } while (false);
     if (done.handle) hsa_signal_destroy(done);
@@ -531,6 +536,12 @@ AqlChain* aql_create(int hip_device, std::string* why)
     }
     if (ok) ok = hipStreamSynchronize(nullptr) == hipSuccess; // (the two hipMemset calls above; nothing else of the process is waited for)
     if (ok) ok = hsa_signal_create(1, 0, nullptr, &ch->done) == HSA_STATUS_SUCCESS;
+    if (ok) {
+        void* p = nullptr;
+        ok = hipMalloc(&p, 64) == hipSuccess && hipMemset(p, 0, 64) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+        ch->xcc_table = static_cast<uint32_t*>(p);
+        if (!ok) *why = "hipMalloc (XCD table) failed";
+    }
     if (ok && c->concurrent_handover == 0) ch->sync_mode = ch->forced_sync = true;
     if (ok && std::getenv("GYMRS_AQL_SYNC")) { // (developer knob: synchronous hand-over everywhere)
         ch->sync_mode = ch->forced_sync = true;
@@ -583,6 +594,7 @@ void aql_destroy(AqlChain* c)
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
+    if (c->xcc_table) (void)hipFree(c->xcc_table);
     if (c->in_flag) (void)hipFree(c->in_flag);
     if (c->out_flag) (void)hipFree(c->out_flag);
     if (c->host_err) (void)hipHostFree(c->host_err);
@@ -719,14 +731,7 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream)
     return note;
 }
 
-uint32_t aql_xcc_map(const AqlChain* c)
-{
-    uint32_t map = c->ctx->xcc_map;
-    // (test hook, tests/test_gpu_aql_chain.py: a table rotated by one entry makes every production launch find itself on the "wrong" XCD)
-    if (const char* v = std::getenv("GYMRS_AQL_TEST_WRONG_XCC"))
-        if (v[0] == '1') map = (map >> 4) | (map << 28);
-    return map;
-}
+uint32_t* aql_xcc_table(const AqlChain* c) { return c->xcc_table; }
 
 uint32_t aql_take_error(AqlChain* c)
 {

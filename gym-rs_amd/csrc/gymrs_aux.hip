@@ -386,51 +386,34 @@ hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, ui
     return hipGetLastError();
 }
 
-// gymrs_copy_probe (measurement): the plain copy a step launch of the same size is compared with.  Shaped like the
-// step kernel: a work-item moves kProbeItems 16-byte items (its loads are all in flight before its first store), a
-// workgroup a contiguous chunk of 256 * kProbeItems items -- 2^20 CartPole lanes' traffic is then ~1300 workgroups of 4 waves.
-constexpr int kProbeItems = 4;
-
-template <bool NT>
-__global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* __restrict__ src, uint64_t n_read16, uint32_t* __restrict__ dst,
+// gymrs_copy_probe (measurement): the plain copy a step launch of the same size is compared with (copy_probe_body,
+// gymrs_tile.h).  Two shapes: at a step's footprint a work-item moves 4 items like the step kernel's tiles; from 1.5 GiB per launch on
+// (the HBM figure: 1 GiB + 1 GiB) one item per work-item -- measured on MI355X (profiles/r04_hbm_probe.log): 6.61 TB/s against 6.24 for the 4-item
+// shape and 5.9-6.1 for every persistent grid-stride form; the guide's own float4 copy reads 6.29.
+template <bool NT, int ITEMS>
+__global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* src, uint64_t n_read16, uint32_t* dst,
                                                             uint64_t n_write16)
 {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const uint64_t first = (uint64_t)blockIdx.x * (kBlock * kProbeItems) + threadIdx.x;
-    u4 v[kProbeItems];
-#pragma unroll
-    for (int j = 0; j < kProbeItems; ++j) {
-        const uint64_t i = first + (uint64_t)j * kBlock;
-        v[j] = u4{(uint32_t)i, 1u, 2u, 3u};
-        if (i < n_read16) v[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i) : reinterpret_cast<const u4*>(src)[i];
-    }
-#pragma unroll
-    for (int j = 0; j < kProbeItems; ++j) {
-        const uint64_t i = first + (uint64_t)j * kBlock;
-        if (i < n_write16) {
-            if (NT)
-                __builtin_nontemporal_store(v[j], reinterpret_cast<u4*>(dst) + i);
-            else
-                reinterpret_cast<u4*>(dst)[i] = v[j];
-        } else if (v[j].x == 0xdeadbeefu && v[j].y == 0x12345678u) { // keeps the load alive when nothing is written for this item
-            dst[0] = v[j].z;
-        }
-    }
+    copy_probe_body<NT, ITEMS>(src, n_read16, dst, n_write16);
 }
 
 hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream)
 {
     const uint64_t items = n_read16 > n_write16 ? n_read16 : n_write16;
     if (items == 0) return hipSuccess;
-    const uint64_t per_block = (uint64_t)kBlock * kProbeItems;
+    const bool big = (n_read16 + n_write16) * 16 >= kCopyProbeBigBytes;
+    const uint64_t per_block = (uint64_t)kBlock * (big ? 1 : kCopyProbeItems);
     const uint64_t grid = (items + per_block - 1) / per_block;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    if (non_temporal)
-        hipLaunchKernelGGL(copy_probe_kernel<true>, dim3((uint32_t)grid), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src), n_read16,
-                           static_cast<uint32_t*>(dst), n_write16);
-    else
-        hipLaunchKernelGGL(copy_probe_kernel<false>, dim3((uint32_t)grid), dim3(kBlock), 0, stream, static_cast<const uint32_t*>(src), n_read16,
-                           static_cast<uint32_t*>(dst), n_write16);
+    const uint32_t* s = static_cast<const uint32_t*>(src);
+    uint32_t* d = static_cast<uint32_t*>(dst);
+    if (big) {
+        if (non_temporal) hipLaunchKernelGGL((copy_probe_kernel<true, 1>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
+        else hipLaunchKernelGGL((copy_probe_kernel<false, 1>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
+    } else {
+        if (non_temporal) hipLaunchKernelGGL((copy_probe_kernel<true, kCopyProbeItems>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
+        else hipLaunchKernelGGL((copy_probe_kernel<false, kCopyProbeItems>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
+    }
     return hipGetLastError();
 }
 

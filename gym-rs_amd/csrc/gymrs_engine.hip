@@ -153,8 +153,11 @@ struct gymrs_engine {
     AqlChain* aql = nullptr;
     bool aql_tried = false;
     bool chain_open = false; // gymrs_step_many is inside aql_begin .. aql_end: see stream_op_barrier
+    bool chain_first = false; // the next step launch is the first of the open chain: it records the XCD table (StepArgs::xcc_table)
     std::string aql_why, aql_handover;
     uint64_t aql_chains = 0, aql_launches = 0; // for the serde view's engine extras (tests, diagnostics)
+    uint32_t last_flags = 0;                   // launch flags (engine flags | hint bits) of the most recent per-step launch ...
+    int last_path = 0;                         // ... and how it was submitted: 0 none yet, 1 HIP launch, 2 chain (the extras' "last_launch")
     uint64_t limit_elided_launches = 0; // for the serde view's engine extras (tests, diagnostics)
     uint64_t age_refreshes = 0, age_waits = 0, age_wait_ns = 0;
 };
@@ -225,12 +228,21 @@ static uint64_t bytes_per_step(const gymrs_engine* e)
     return e->n * bytes_per_lane;
 }
 
+// Round 4 (profiles/r04_hints_by_size.log, per class of access): between those two regimes it is only the stores nobody reads
+// again -- reward, done, truncated, Pendulum's cos / sin -- that should be streamed: they then leave the Infinity Cache to the state, which
+// the next step reads (CartPole 2^21 lanes 13.3 -> 12.1 us, 2^23 56.2 -> 49.0, 2^24 112.2 -> 96.0 against hinting everything, which is
+// what round 3 did from 340 MiB per step on).  Only beyond ~1 GiB per step does hinting every access win again (2^25 lanes: 231 vs 242 us).
 static uint32_t launch_flags_of(const gymrs_engine* e)
 {
     const uint64_t per_step = bytes_per_step(e);
-    const bool streaming = per_step <= (48ull << 20) || per_step >= (340ull << 20);
-    const bool nt = e->nt_mode == 1 || (e->nt_mode == 0 && streaming);
-    return e->flags | (nt ? kFlagNonTemporal : 0u);
+    uint32_t hint = 0;
+    switch (e->nt_mode) {
+    case 1: hint = kFlagNonTemporal; break;
+    case 2: hint = 0; break;
+    case 3: hint = kFlagNtOut; break;
+    default: hint = (per_step <= (48ull << 20) || per_step >= (1024ull << 20)) ? kFlagNonTemporal : kFlagNtOut; break;
+    }
+    return e->flags | hint;
 }
 
 static StepArgs step_args(const gymrs_engine* e, const void* actions)
@@ -428,7 +440,7 @@ static gymrs_status flags_for_step(gymrs_engine* e, uint32_t* out)
         } else {
             const uint32_t run = g_stepper_run[e->device].exchange(1, std::memory_order_relaxed);
             // taking over the device from an engine that ran for a while (or first launch): install the lines, see above
-            if ((prev == nullptr || run >= kTakeOverAfter) && e->nt_mode == 0) flags &= ~kFlagNonTemporal;
+            if ((prev == nullptr || run >= kTakeOverAfter) && e->nt_mode == 0) flags &= ~kFlagHintMask;
         }
     }
     *out = flags;
@@ -940,7 +952,7 @@ gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_
     if (!e) return fail(GYMRS_EINVAL, "gymrs_set_tuning: engine is NULL");
     if (lanes_per_thread != 4 && lanes_per_thread != 8)
         return fail(GYMRS_EINVAL, "gymrs_set_tuning: lanes_per_thread must be 4 or 8");
-    if (memory_hint < 0 || memory_hint > 2) return fail(GYMRS_EINVAL, "gymrs_set_tuning: memory_hint must be 0, 1 or 2");
+    if (memory_hint < 0 || memory_hint > 3) return fail(GYMRS_EINVAL, "gymrs_set_tuning: memory_hint must be 0, 1, 2 or 3");
     e->vec = lanes_per_thread;
     e->nt_mode = memory_hint;
     return GYMRS_OK;
@@ -1123,6 +1135,8 @@ gymrs_status gymrs_step(gymrs_engine* e, const void* actions_dev)
     StepArgs a = step_args(e, actions_dev);
     if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return st;
     HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
+    e->last_flags = flags;
+    e->last_path = 1;
     e->tick += 1;
     if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
     if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick; // all lanes were re-armed
@@ -1285,6 +1299,7 @@ static uint32_t chain_hint_bits(const gymrs_engine* e)
 {
     if (e->nt_mode == 1) return kFlagNonTemporal;
     if (e->nt_mode == 2) return 0u;
+    if (e->nt_mode == 3) return kFlagNtOut;
     const uint64_t per_step = bytes_per_step(e);
     if (per_step >= (340ull << 20)) return kFlagNonTemporal;
     return per_step <= (48ull << 20) ? (kFlagNtOut | kFlagNtStateLoads) : kFlagNtOut;
@@ -1347,19 +1362,23 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     if (e->reset_log && e->log_pending != 0 && e->log_vec != e->vec) {
         if (gymrs_status st = fold_reset_log(e)) return st;
     }
+    // (test hook, tests/test_gpu_aql_chain.py: a table nobody's XCC matches -- and no recording launch -- stands in for a deal that changed
+    // in mid-chain; the memset sits on the stream ahead of the hand-over into the chain)
+    const char* wrong = std::getenv("GYMRS_AQL_TEST_WRONG_XCC");
+    const bool poisoned = wrong && wrong[0] == '1';
+    if (poisoned) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(aql_xcc_table(e->aql)), 0x11, 8, e->stream));
     if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched, no host state touched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
         aql_destroy(e->aql);
         e->aql = nullptr;
         return GYMRS_OK;
     }
-    e->chain_open = true;
+    e->chain_open = e->chain_first = true;
     *taken = true;
     int threads = step_threads_of(e->kind, e->n, e->vec);
     if (const char* v = std::getenv("GYMRS_DEV_THREADS")) // (developer knob: 256 work-items per workgroup for CartPole chains)
         if (e->kind == GYMRS_CARTPOLE && std::atoi(v) == kBlock) threads = kBlock;
     uint32_t last_key = ~0u;
-    const uint32_t xcc_map = aql_xcc_map(e->aql);
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
         const std::string msg = g_last_error;
@@ -1375,12 +1394,10 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
         flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
-        a.xcc_map = xcc_map; // every wavefront of a chain launch checks where it runs (StepArgs::xcc_map)
-        a.xcc_check = 1u;
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
         if (!e->chain_open) { // (the host side of this step closed the chain: the step opens the next one)
             if (!aql_begin(e->aql, e->stream, &err)) return fail(GYMRS_EHIP, "AQL dispatcher: " + err);
-            e->chain_open = true;
+            e->chain_open = e->chain_first = true;
         }
         const uint32_t key = (flags & kFlagHintMask) | (flags & (GYMRS_AUTO_RESET | GYMRS_TRACK_STATS | GYMRS_TIME_LIMIT));
         if (key != last_key) {
@@ -1388,6 +1405,10 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
             if (name.empty() || !aql_kernel(e->aql, name.c_str(), &k)) return bail(fail(GYMRS_EHIP, "AQL dispatcher: no kernel for this launch"));
             last_key = key;
         }
+        // every wavefront of a chain launch checks where it runs; the chain's first launch records the table (StepArgs::xcc_table)
+        a.xcc_table = aql_xcc_table(e->aql);
+        a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
+        e->chain_first = false;
         bool ok = false;
         switch (e->kind) {
         case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err); break;
@@ -1395,6 +1416,8 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err); break;
         }
         if (!ok) return bail(fail(GYMRS_EHIP, "AQL dispatcher: " + err));
+        e->last_flags = flags;
+        e->last_path = 2;
         e->tick += 1;
         if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
         if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
@@ -1465,6 +1488,8 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return st;
         HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
+        e->last_flags = flags;
+        e->last_path = 1;
         e->tick += 1;
         if (e->kind == GYMRS_PENDULUM && (e->flags & GYMRS_TIME_LIMIT)) e->trunc_held = (int)a.truncate_all;
         if (a.truncate_all && (e->flags & GYMRS_AUTO_RESET)) e->uniform_start = e->tick;
@@ -2004,6 +2029,19 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
     // chains of per-step launches that went through the engine's own AQL dispatcher (gymrs_aql.h), and why not if none can
     g.uint("aql_chains", e->aql_chains).uint("aql_launches", e->aql_launches);
     if (e->aql) g.str("aql_handover", e->aql_handover.c_str());
+    if (e->last_path != 0) { // the most recent per-step launch as a kernel trace names it
+        const int threads = step_threads_of(e->kind, e->n, e->vec);
+        const uint32_t h = e->last_flags & kFlagHintMask;
+        const char* hint = (h & kFlagNonTemporal) ? "nt" : (h == (kFlagNtOut | kFlagNtStateLoads) ? "so" : (h == kFlagNtOut ? "o" : "pl"));
+        char buf[160];
+        if (e->last_path == 2)
+            std::snprintf(buf, sizeof(buf), "chain: %s", aql_kernel_name(e, e->last_flags, threads).c_str());
+        else
+            std::snprintf(buf, sizeof(buf), "HIP launch: gymrs::step_kernel<%s, %d, flags %u | hint %s, %d work-items>",
+                          e->kind == GYMRS_CARTPOLE ? "CartPoleT" : (e->kind == GYMRS_MOUNTAIN_CAR ? "MountainCarT" : "PendulumT"), e->vec,
+                          e->last_flags & 7u, hint, threads);
+        g.str("last_launch", buf);
+    }
     g.str("aql", e->aql ? "on" : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
     if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
         g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
@@ -2190,39 +2228,86 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* text, void*
 }
 
 // ---- measurement -------------------------------------------------------------------------------------------------------
-gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int non_temporal,
+gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int mode,
                               double* us_per_launch)
 {
     if (!us_per_launch || launches == 0) return fail(GYMRS_EINVAL, "gymrs_copy_probe: NULL output or zero launches");
+    if (mode < 0 || mode > 3) return fail(GYMRS_EINVAL, "gymrs_copy_probe: mode must be 0 .. 3 (bit 0: non-temporal accesses, bit 1: through a chain)");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GYMRS_EHIP, "gymrs_copy_probe: no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(GYMRS_EINVAL, "gymrs_copy_probe: device index out of range");
     HIP_TRY(hipSetDevice(device));
+    const int non_temporal = mode & 1;
+    const bool chained = (mode & 2) != 0;
     const uint64_t n_read = read_bytes / 16, n_write = write_bytes / 16;
+    const bool big = (n_read + n_write) * 16 >= kCopyProbeBigBytes;
+    if (chained && big) return fail(GYMRS_EINVAL, "gymrs_copy_probe: the chained form is for a step's footprint (< 1.5 GiB per launch)");
     void *src = nullptr, *dst = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipError_t err = hipMalloc(&src, n_read * 16 + 256);
-    if (err == hipSuccess) err = hipMalloc(&dst, n_write * 16 + 256);
-    if (err == hipSuccess) err = hipMemset(src, 0, n_read * 16 + 256);
+    AqlChain* chain = nullptr;
+    std::string why;
+    // At a step's footprint the copy works IN PLACE like a step does: the bytes it reads are the first bytes it writes (a step updates its
+    // state where it lies and adds its outputs) -- inside a chain that is what lets the lines stay in the L2s.  The HBM figure
+    // (>= 1.5 GiB per launch) copies from one buffer into another.
+    const uint64_t span = (n_read > n_write ? n_read : n_write) * 16 + 256;
+    hipError_t err = hipMalloc(&src, big ? n_read * 16 + 256 : span);
+    if (err == hipSuccess && big) err = hipMalloc(&dst, n_write * 16 + 256);
+    if (err == hipSuccess && !big) dst = src;
+    if (err == hipSuccess) err = hipMemset(src, 0, big ? n_read * 16 + 256 : span);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking);
     if (err == hipSuccess) err = hipEventCreate(&ev0);
     if (err == hipSuccess) err = hipEventCreate(&ev1);
+    bool chain_failed = false;
+    AqlKernel k;
+    if (err == hipSuccess && chained) {
+        // the same copy as launches of a CHAIN on a dispatcher queue of its own (acquire only, the release at the end of the chain): what a
+        // chain's step has to be compared with -- the HIP-launched copy carries a release fence per launch, a chain's step does not
+        chain = aql_create(device, &why);
+        if (!chain || !aql_kernel(chain, non_temporal ? "gymrs_aql_copy_probe_nt" : "gymrs_aql_copy_probe_pl", &k)) chain_failed = true;
+        if (!chain_failed) (void)aql_calibrate(chain, stream, true);
+    }
+    auto run = [&](uint32_t count) -> hipError_t {
+        if (!chained) {
+            hipError_t e2 = hipSuccess;
+            for (uint32_t i = 0; i < count && e2 == hipSuccess; ++i) e2 = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+            return e2;
+        }
+        const uint64_t items = n_read > n_write ? n_read : n_write;
+        const uint64_t per_block = (uint64_t)kBlock * kCopyProbeItems;
+        const uint32_t grid = (uint32_t)((items + per_block - 1) / per_block);
+        CopyProbeKernArgs ka{static_cast<const uint32_t*>(src), n_read, static_cast<uint32_t*>(dst), n_write};
+        if (k.kernarg_bytes != sizeof(ka)) {
+            why = "kernel-argument segment of the copy kernel differs from what the dispatcher fills";
+            chain_failed = true;
+            return hipSuccess;
+        }
+        if (!aql_begin(chain, stream, &why)) {
+            chain_failed = true;
+            return hipSuccess;
+        }
+        bool ok = true;
+        for (uint32_t i = 0; i < count && ok; ++i) ok = aql_dispatch(chain, k, grid * (uint32_t)kBlock, (uint32_t)kBlock, &ka, sizeof(ka), &why);
+        if (!aql_end(chain, stream, &why) || !ok) chain_failed = true;
+        return hipSuccess;
+    };
     // warm-up: as many launches again, so that clocks and caches are where a long run has them
-    for (uint32_t i = 0; i < launches + 3 && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+    if (err == hipSuccess && !chain_failed) err = run(launches + 3);
     if (err == hipSuccess) err = hipStreamSynchronize(stream);
     if (err == hipSuccess) err = hipEventRecord(ev0, stream);
-    for (uint32_t i = 0; i < launches && err == hipSuccess; ++i) err = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+    if (err == hipSuccess && !chain_failed) err = run(launches);
     if (err == hipSuccess) err = hipEventRecord(ev1, stream);
     if (err == hipSuccess) err = hipStreamSynchronize(stream);
     float ms = 0.0f;
     if (err == hipSuccess) err = hipEventElapsedTime(&ms, ev0, ev1);
+    if (chain) aql_destroy(chain);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
     (void)hipFree(src);
-    (void)hipFree(dst);
+    if (dst != src) (void)hipFree(dst);
     if (err != hipSuccess) return fail(err == hipErrorOutOfMemory ? GYMRS_ENOMEM : GYMRS_EHIP, std::string("gymrs_copy_probe: ") + hipGetErrorString(err));
+    if (chain_failed) return fail(GYMRS_EHIP, "gymrs_copy_probe: the engine's own dispatcher is not available here (" + why + ")");
     *us_per_launch = (double)ms * 1e3 / (double)launches;
     return GYMRS_OK;
 }

@@ -58,10 +58,13 @@ struct StepArgs {
     uint32_t skip_trunc_store; // same envs: the `truncated` array already holds this step's (uniform) value
     unsigned long long* trace; // developer instrumentation (GYMRS_TRACE_TIMES builds), else NULL
     // Launches of a chain (gymrs_aql.h) carry no release fence between them, which is only right while tile i is stepped on the SAME
-    // XCD (= the same L2) in every launch.  xcc_check != 0: every wavefront compares the XCC it runs on (HW_REG_XCC_ID) with
-    // nibble (blockIdx.x & 7) of xcc_map -- what the dispatcher's self-check saw for that workgroup index on this device -- and
-    // reports a mismatch through err_seen[1].  HIP launches (a release fence each) pass 0.
-    uint32_t xcc_map;
+    // XCD (= the same L2) in every launch of the chain.  Where a queue's workgroups start is NOT a constant of the queue (round 4: it
+    // differs between queues and changes while a queue sits idle), so the premise is checked per chain: the FIRST step launch after
+    // aql_begin (xcc_check == 2) records the XCC of its workgroups 0 .. 7 in xcc_table (written through: `sc1`), every later launch of
+    // the chain (xcc_check == 1) compares the XCC it runs on (HW_REG_XCC_ID) with entry (blockIdx.x & 7) and reports a mismatch through
+    // err_seen[1].  Between two chains everything is written back and re-acquired, so a deal that changed THERE is harmless.  HIP
+    // launches (a release fence each) pass xcc_check == 0.
+    uint32_t* xcc_table; // [8] device words: XCC id + 1 (0 = not recorded: fewer than 8 workgroups)
     uint32_t xcc_check;
     uint32_t trace_wpb; // wavefronts per workgroup of this launch (the stamps' index; blockDim would be a hidden kernel argument, which
                         // the engine's own dispatcher does not supply)
@@ -170,7 +173,16 @@ hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
 // device words of scratch; the result goes to host_out2 (device-visible host memory): [0] = the age, then [1] = seq.
 hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
                           hipStream_t stream);
-// gymrs_copy_probe: one work-item per 16 bytes; reads n_read16 and writes n_write16 16-byte items
+// gymrs_copy_probe: reads n_read16 and writes n_write16 16-byte items; kCopyProbeItems items per work-item, one from
+// kCopyProbeBigBytes per launch on (gymrs_aux.hip says why)
+constexpr int kCopyProbeItems = 4;
+constexpr uint64_t kCopyProbeBigBytes = 1536ull << 20;
+struct CopyProbeKernArgs { // the kernel-argument segment of the copy probe's kernels as the engine's own dispatcher fills it
+    const uint32_t* src;
+    uint64_t n_read16;
+    uint32_t* dst;
+    uint64_t n_write16;
+};
 hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream);
 
 } // namespace gymrs

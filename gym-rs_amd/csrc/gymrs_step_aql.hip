@@ -38,6 +38,16 @@ GYMRS_AQL_STEP_FLAGSETS(cartpole, CartPoleT, 256)
 GYMRS_AQL_STEP_FLAGSETS(mountain_car, MountainCarT, 256)
 GYMRS_AQL_STEP_FLAGSETS(pendulum, PendulumT, 256)
 
+// ---- the copy probe's kernel (gymrs_copy_probe through a chain: the floor a chain's step is compared with) ---------------------
+extern "C" __global__ __launch_bounds__(kBlock) void gymrs_aql_copy_probe_pl(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)
+{
+    copy_probe_body<false, kCopyProbeItems>(src, n_read16, dst, n_write16);
+}
+extern "C" __global__ __launch_bounds__(kBlock) void gymrs_aql_copy_probe_nt(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)
+{
+    copy_probe_body<true, kCopyProbeItems>(src, n_read16, dst, n_write16);
+}
+
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put
 // behind everything that was enqueued there before (flag >= seq, wrap-around safe).  Bounded: a stream that never gets

@@ -173,18 +173,26 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
     // straddles n (and the empty ones behind it) takes the guarded per-lane code.  n_fast (a preloaded scalar
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
+    // (chains only, StepArgs::xcc_table) what the first launch of this chain recorded for this workgroup index: fetched here, a scalar
+    // load next to the kernel-argument fetch, compared after the stores have been issued
+    uint32_t xcc_want = 0;
+    if (rest.xcc_check == 1u) xcc_want = rest.xcc_table[blockIdx.x & 7u];
     if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
         step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
     else
         step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
     // A launch of a chain: no release fence separates it from the next one, so this tile's lines must be found in THIS XCD's L2 by the
-    // next launch's workgroup of the same index (gymrs_aql.h).  The premise is checked where it matters, in every production launch,
-    // after the stores have been issued: a handful of scalar instructions per wavefront (kernel argument, blockIdx, one s_getreg).
-    if (rest.xcc_check != 0) {
+    // next launch's workgroup of the same index (gymrs_aql.h).  The premise is checked where it matters, in every production launch: a
+    // handful of scalar instructions per wavefront (one s_getreg, one scalar load, a compare).
+    if (rest.xcc_check != 0u) {
         uint32_t id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        const uint32_t want = (rest.xcc_map >> ((blockIdx.x & 7u) * 4u)) & 0xfu;
-        if ((id & 0xfu) != want && (threadIdx.x & 63u) == 0) rest.err_seen[1] = blockIdx.x + 1u;
+        id = (id & 0xfu) + 1u;
+        if (rest.xcc_check == 2u) { // first launch of the chain: workgroups 0 .. 7 write the table through (agent scope: `sc1`)
+            if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(&rest.xcc_table[blockIdx.x], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (xcc_want != 0u && xcc_want != id && (threadIdx.x & 63u) == 0) {
+            rest.err_seen[1] = blockIdx.x + 1u;
+        }
     }
 }
 
@@ -246,11 +254,14 @@ static hipError_t launch_flags_nt(uint32_t flags, const StepArgs& a, const void*
     }
 }
 
+// hint variants of a HIP launch: every access (small batches and far beyond the caches), only the stores nobody reads again
+// (kFlagNtOut: in between, profiles/r04_hints_by_size.log), none
 template <class Env, int VEC>
 static hipError_t launch_flags(uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream)
 {
-    return (flags & kFlagNonTemporal) ? launch_flags_nt<Env, VEC, kFlagNonTemporal>(flags, a, consts, stream)
-                                      : launch_flags_nt<Env, VEC, 0u>(flags, a, consts, stream);
+    if (flags & kFlagNonTemporal) return launch_flags_nt<Env, VEC, kFlagNonTemporal>(flags, a, consts, stream);
+    if (flags & kFlagNtOut) return launch_flags_nt<Env, VEC, kFlagNtOut>(flags, a, consts, stream);
+    return launch_flags_nt<Env, VEC, 0u>(flags, a, consts, stream);
 }
 
 template <class Env>

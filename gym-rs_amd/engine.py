@@ -184,7 +184,7 @@ class BatchedEngine:
         _check(self._lib, self._lib.gymrs_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_tuning(self, lanes_per_thread: int = 4, memory_hint: int = 0) -> None:
-        """lanes_per_thread: 4 or 8.  memory_hint: 0 automatic, 1 always non-temporal accesses, 2 never."""
+        """lanes_per_thread: 4 or 8.  memory_hint: 0 automatic, 1 every access non-temporal, 2 none, 3 only the stores nobody reads again."""
         _check(self._lib, self._lib.gymrs_set_tuning(self._h, int(lanes_per_thread), int(memory_hint)))
 
     # -- the pub physics fields after construction; the Serialize view -------------------------------

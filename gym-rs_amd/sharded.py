@@ -402,11 +402,14 @@ class ShardedRun:
             # watched: a native collective that never completes ends this rank loudly (the launcher then ends the others)
             timeout = float(os.environ.get("GYMRS_COMM_TIMEOUT", "90"))
             done, res = call_with_timeout(self.engine.allreduce_stats, timeout)
+            if not done and res is not None:
+                raise res  # an ordinary failure of the C ABI call (a status, a message): the caller decides (this used to end the process)
             if not done:
-                sys.stderr.write(f"gymrs sharded: rank {self.info.rank}: gymrs_allreduce_stats "
-                                 + (f"failed: {res!r}" if res is not None else f"did not complete within {timeout:.0f} s") + "\n")
-                sys.stderr.flush()
-                os._exit(3)
+                # a collective that never completes cannot be cancelled, and its helper thread holds the engine's stream: the rank is marked
+                # abandoned (bench.py then leaves through os._exit after printing; a library user sees the exception) instead of exiting HERE
+                self.abandoned = True
+                raise TimeoutError(f"gymrs sharded: rank {self.info.rank}: gymrs_allreduce_stats did not complete within {timeout:.0f} s "
+                                   f"(a peer never arrived?); the communicator of this engine is unusable from now on")
             return np.asarray(res, dtype=np.float64)
         return self.coll.sum(self.engine.stats())
 

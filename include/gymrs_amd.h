@@ -287,12 +287,14 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* json, void*
 
 /* ---- measurement ("also measure an in-repo stream-copy kernel on the box") ---------- */
 /* Times `launches` back-to-back launches of a plain dwordx4 copy kernel that reads read_bytes and writes write_bytes
- * per launch (private buffers on `device`, four 16-byte items per work-item like the step kernel's tiles, HIP events on a private stream, after as many
- * untimed warm-up launches) and returns the mean microseconds per launch.  With read/write sizes of one step's traffic this is the
- * floor a step launch of that size can reach on this box (it includes the fixed cost of a dependent launch); with
- * sizes beyond the 256 MiB Infinity Cache it is the HBM bandwidth a kernel can actually get.  non_temporal != 0
- * uses nt loads/stores like the step kernel does below 48 MiB per step. */
-gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int non_temporal,
+ * per launch (private buffers on `device`, HIP events on a private stream, after as many untimed warm-up launches) and returns the
+ * mean microseconds per launch.  With read/write sizes of one step's traffic (four 16-byte items per work-item like the step kernel's
+ * tiles, IN PLACE like a step: the bytes read are the first bytes written) this is the floor a step launch of that size can reach on this
+ * box (it includes the fixed cost of a dependent launch); from 1.5 GiB per launch on (1 GiB + 1 GiB: two buffers, one item per work-item,
+ * the shape that streams fastest) it is the HBM bandwidth a kernel can actually get.  mode bit 0: non-temporal loads / stores; bit 1: the launches go through a chain of the
+ * library's own dispatcher (acquire-only packets, one release at the end: what gymrs_step_many's chains must be compared with; a
+ * step's footprint only; GYMRS_EHIP where the dispatcher is not available). */
+gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int mode,
                               double* us_per_launch);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
@@ -303,9 +305,9 @@ gymrs_status gymrs_fill_actions(gymrs_engine* e, void* actions_dev, uint64_t see
 /* Engine tick (number of reset()/step() calls since the last seeded reset) and current seed. */
 gymrs_status gymrs_get_tick(gymrs_engine* e, uint64_t* tick, uint64_t* seed);
 /* Kernel tuning knobs for benchmarks; results never depend on them.  lanes_per_thread: 4 (default) or 8
- * lanes per work-item (16 was measured 4x slower everywhere and was removed in ABI 2).  memory_hint: 0 = automatic (non-temporal loads/stores while one step's traffic is
- * <= 48 MiB or >= 340 MiB; plain in between, where the Infinity Cache still serves part of the next step), 1 = always
- * non-temporal, 2 = never. */
+ * lanes per work-item (16 was measured 4x slower everywhere and was removed in ABI 2).  memory_hint: 0 = automatic (every access non-temporal while one step's traffic is
+ * <= 48 MiB or >= 1 GiB; in between only the stores nobody reads again -- reward, flags, Pendulum's cos / sin -- so that the Infinity
+ * Cache keeps the state for the next step), 1 = every access non-temporal, 2 = none, 3 = only those stores. */
 gymrs_status gymrs_set_tuning(gymrs_engine* e, int lanes_per_thread, int memory_hint);
 
 const char* gymrs_last_error(void);

@@ -45,7 +45,18 @@ def check_common(d, n_gpus, steps, warmup, min_ms=3.5, min_frac=0.05):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"])
     assert r["achieved"] == pytest.approx(r["bytes_per_launch"] / (r["launch_us"] * 1e-6) / 1e9)
-    assert min_frac < r["frac"] < 1.3
+    # a fraction of a roofline is at most 1: the headline times the call shape that does the per-step round trip (VERDICT r3 "next" #1)
+    assert min_frac < r["frac"] <= 1.0
+    assert d["config"]["call_shape"] == "per_step_visible" and d["roofline"] == d["paths"]["per_step_visible"]["roofline"]
+    assert d["value"] == d["paths"]["per_step_visible"]["value"]
+    if "chain" in d["paths"]:  # reported separately, against the bound that applies to a cache-resident chain
+        c = d["paths"]["chain"]
+        assert c["roofline"]["bound"] == "l2" and c["roofline"]["peak"] == 34500.0 and 0 < c["roofline"]["frac"] <= 1.0
+        assert "reported_separately" in c
+    for p in d["paths"].values():  # traffic: a figure taken on THAT call shape with exactly these kernel sources, or null with the reason
+        pr = p["roofline"]
+        assert (pr["traffic"] is None and "traffic_note" in pr) or (pr["traffic"] > 0 and "frac_moved" in pr and "traffic_source" in pr)
+    assert d["ranks_agree"] is True
     # the event-derived launch time cannot exceed the wall time per step
     assert r["launch_us"] <= d["ms_per_step"] * 1e3 * 1.001
     assert [x["rank"] for x in d["ranks"]] == list(range(n_gpus))
@@ -54,50 +65,72 @@ def check_common(d, n_gpus, steps, warmup, min_ms=3.5, min_frac=0.05):
     assert [x["global_env_offset"] for x in d["ranks"]] == [k * d["config"]["lanes_per_gpu"] for k in range(n_gpus)]
 
 
-def test_the_drivers_own_command_reports_the_kernel_limited_rate():
-    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` printed 7.46e10 because a 40 us statistics
-    read-out and its syncs sat inside a 0.28 ms wall-clock window.  Now: value >= 1.4e11 and ms_per_step within 10 % of
-    the HIP-event launch time."""
-    d = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"])
+@pytest.fixture(scope="module")
+def driver_line():
+    """The driver's own command, run once for the tests below."""
+    return run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--cpu-seconds", "1"])
+
+
+CONFIGS = {"mountain_car_2p20": 1 << 20, "pendulum_2p22": 1 << 22, "pendulum_2p22_8_action_buffers": 1 << 22,
+           "cartpole_2p24_dram_resident": 1 << 24, "cartpole_2p25_hbm_streaming": 1 << 25}
+
+
+def test_the_drivers_own_command_prints_a_well_formed_line(driver_line):
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5`: the contract's fields, BOTH call shapes, every other BASELINE config as a
+    sub-record, rooflines that are fractions (<= 1) of a stated peak with the traffic of the call shape they describe."""
+    d = driver_line
     check_common(d, 1, 20, 5)
-    # >= 9 repetitions taken in the settled state: they agree (VERDICT r2 "next" #2 asks for 2 %; 4 % leaves room for a box's noise)
     assert d["timing"]["repetitions"] >= 9 and d["timing"]["settle_ms"] >= 50.0
-    assert d["timing"]["event_us_per_step"]["spread"] < 0.04, d["timing"]["event_us_per_step"]
-    # the other BASELINE.json configs ride on the same line (VERDICT r2 "next" #3)
+    assert set(d["paths"]) == {"per_step_visible", "chain"}
     cfgs = d["configs"]
-    assert set(cfgs) == {"mountain_car_2p20", "pendulum_2p22", "cartpole_2p24_dram_resident"}
-    assert cfgs["mountain_car_2p20"]["lanes"] == 1 << 20 and cfgs["pendulum_2p22"]["lanes"] == 1 << 22 and cfgs["cartpole_2p24_dram_resident"]["lanes"] == 1 << 24
+    assert set(cfgs) == set(CONFIGS)
     for name, c in cfgs.items():
+        assert c["lanes"] == CONFIGS[name] and c["call_shape"] == "per_step_visible" and set(c["paths"]) == {"per_step_visible", "chain"}
         assert c["value"] == pytest.approx(c["lanes"] / (c["launch_us"] * 1e-6)) and c["launch_us_min"] <= c["launch_us"] <= c["launch_us_max"]
-        assert c["frac"] == pytest.approx(c["lanes"] * c["bytes_per_env_step"] / (c["launch_us"] * 1e-6) / 1e9 / 8000.0)
-        assert 0.3 < c["frac"] < 1.3 and 0.5 < c["frac_of_same_footprint_copy"] < 1.6, (name, c)
-    assert cfgs["mountain_car_2p20"]["value"] > 1.5e11 and cfgs["pendulum_2p22"]["value"] > 1.0e11 and cfgs["cartpole_2p24_dram_resident"]["value"] > 1.0e11
+        for path, p in c["paths"].items():
+            r = p["roofline"]
+            assert r["frac_counted"] == pytest.approx(c["lanes"] * c["bytes_per_env_step"] / (p["launch_us"] * 1e-6) / 1e9 / r["peak"])
+            assert 0 < r["frac"] <= 1.0 and 0 < r["frac_counted"] <= 1.0, (name, path, r)
+            assert "same_footprint_copy_us" in r
+    assert cfgs["pendulum_2p22"]["action_buffers"] == 32 and cfgs["pendulum_2p22_8_action_buffers"]["action_buffers"] == 8
     assert d["config"]["lanes_per_gpu"] == 1 << 20 and "CartPole" in d["config"]["workload"]
-    assert d["value"] >= 1.4e11, d["value"]
-    assert d["ms_per_step"] * 1e3 <= d["roofline"]["launch_us"] * 1.10, (d["ms_per_step"], d["roofline"]["launch_us"])
-    assert d["timing"]["stats_readout_us"] < 1000.0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "env-steps/s" and c["value"] > 1e6 and c["sample"]
-    assert d["value"] > 100 * c["value"]
     assert d["episodes"]["n_episodes"] > 0
     pm = d["roofline"]["peak_measured"]
-    # (the copy probe is HIP-launched, release fence and all: a chain's step can be FASTER than the copy of its own footprint)
-    assert 3000 < pm["hbm_copy_GBps"] < 8000 and 2.0 < pm["same_footprint_copy_us"] < 10.0
-    assert 0.5 < d["roofline"]["frac_of_same_footprint_copy"] <= 1.6
-    # the headline runs through the engine's own dispatcher; a box on which its self-check fails (no large-BAR access to device
-    # memory, ...) runs HIP launches, says why, and is held to round 2's rate
-    chained = d["config"]["submission"].startswith("AQL chains")
-    print("submission:", d["config"]["submission"])
-    assert d["value"] >= (1.9e11 if chained else 1.4e11), (d["value"], d["config"]["submission"])
+    assert 3000 < pm["hbm_copy_GBps"] < 8000
+    print("submission:", {k: v["submission"] for k, v in d["paths"].items()})
+
+
+@pytest.mark.perf
+def test_the_drivers_own_command_reports_the_kernel_limited_rate(driver_line):
+    """The RATES of that line (a perf test: runs after every correctness test).  VERDICT r1 next #1: the driver's command printed 7.46e10
+    because a 40 us statistics read-out and its syncs sat inside a 0.28 ms wall-clock window."""
+    d = driver_line
+    # >= 9 repetitions taken in the settled state: they agree (VERDICT r2 "next" #2 asks for 2 %; 4 % leaves room for a box's noise)
+    assert d["timing"]["event_us_per_step"]["spread"] < 0.04, d["timing"]["event_us_per_step"]
+    assert d["value"] >= 1.4e11, d["value"]   # per-step visible: HIP launches, a release fence each
+    assert d["ms_per_step"] * 1e3 <= d["roofline"]["launch_us"] * 1.10, (d["ms_per_step"], d["roofline"]["launch_us"])
+    assert d["timing"]["stats_readout_us"] < 1000.0
+    assert d["value"] > 100 * d["cpu_baseline"]["value"]
+    chain = d["paths"]["chain"]
+    if chain["submission"].startswith("AQL chains"):  # (a box on which the dispatcher's self-check fails runs HIP launches there too, and says so)
+        assert chain["value"] >= 1.9e11, chain["value"]
+        assert chain["value"] > d["value"]
+    cfgs = d["configs"]
+    assert cfgs["mountain_car_2p20"]["value"] > 1.5e11 and cfgs["pendulum_2p22"]["value"] > 1.0e11 and cfgs["cartpole_2p24_dram_resident"]["value"] > 1.0e11
+    # a step cannot beat a plain copy of its own footprint submitted the same way (a few % of timing noise between two measurements)
+    for p in d["paths"].values():
+        assert 0.5 < p["roofline"]["frac_of_same_footprint_copy"] <= 1.05, p["roofline"]
+    for name, c in cfgs.items():
+        for path, p in c["paths"].items():
+            assert 0.5 < p["roofline"]["frac_of_same_footprint_copy"] <= 1.08, (name, path, p["roofline"])
 
 
 def test_default_form_prints_the_contract_line():
     d = run([sys.executable, "bench.py", "--steps", "300", "--warmup", "50", "--cpu-seconds", "0", "--no-probe"])
     check_common(d, 1, 300, 50)
-    assert "cpu_baseline" not in d and "peak_measured" not in d["roofline"]
-    # traffic is either a figure collected with exactly these kernel sources or null with the reason
-    r = d["roofline"]
-    assert (r["traffic"] is None and "traffic_note" in r) or (r["traffic"] > 0.9 * r["bytes_per_launch"] and "frac_moved" in r)
+    assert "cpu_baseline" not in d and "peak_measured" not in d["roofline"] and "same_footprint_copy_us" not in d["roofline"]
 
 
 def test_torchrun_form_with_one_rank_uses_the_native_rccl_path():
@@ -153,6 +186,10 @@ def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     assert len(eight["ranks"]) == 8 and eight["config"]["total_lanes"] == 8 * lanes
     assert eight["cpu_baseline"]["kind"] == "port" and eight["cpu_baseline"]["value"] > 1e6  # an N > 1 line carries it too
     assert eight["roofline"]["bound"] == "hbm" and eight["config"]["comm_watchdog"] == "not triggered"
+    # every rank says how it submits each call shape, and the line says whether they agree (VERDICT r3 "next" #8)
+    assert eight["ranks_agree"] in (True, False) and all(set(r["paths"]) == {"per_step_visible", "chain"} for r in eight["ranks"])
+    assert eight["ranks_agree"] == (len({(r["paths"]["chain"]["submission"], (r["paths"]["chain"]["handover"] or "").split(" (")[0]) for r in eight["ranks"]}) == 1)
+    assert eight["expected_job_rate_from_rank_launch_times"] > 0
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", str(8 * lanes), "--cpu-seconds", "0", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == eight["timing"]["passes_per_repetition"] == 2
     assert one["timing"]["calibration_passes"] == eight["timing"]["calibration_passes"]

@@ -144,6 +144,35 @@ def test_step_many_equals_repeated_step(gymrs, twin):
     assert eng.tick()[0] == steps + 1
     eng.close()
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("hint", [1, 2, 3])
+def test_memory_hints_never_change_results(gymrs, twin, kind, hint):
+    """gymrs_set_tuning's memory_hint picks another instantiation of the same kernel (1 every access non-temporal, 2 none, 3 only the
+    stores nobody reads again -- what the engine uses between 48 MiB and 1 GiB per step): HIP launches (gymrs_step) and chains
+    (gymrs_step_many) of each must produce the twin's bits."""
+    n, nbuf = 9001, 4
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if kind == 2 else 0)
+    eng = gymrs.BatchedEngine(kind, n, flags=flags)
+    eng.set_tuning(4, hint)
+    tw = TwinEngine(twin, kind, n, eng.params, flags=flags)
+    eng.reset(seed=9)
+    tw.reset(9)
+    bufs = torch.empty((nbuf, n), dtype=torch.float32 if kind == 2 else torch.uint8, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(bufs[b].data_ptr(), seed=3, t=b)
+    for t in range(11):
+        eng.step(bufs[t % nbuf].data_ptr())
+    eng.step_many(bufs.data_ptr(), bufs.stride(0) * bufs.element_size(), nbuf, 29)
+    eng.sync()
+    for t in list(range(11)) + list(range(29)):
+        tw.step(tw.fill_actions(3, t % nbuf))
+    assert np.array_equal(eng.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+    r, d, tr = eng.get_step_result()
+    tr_, td, tt = tw.get_result()
+    assert np.array_equal(d, td) and np.array_equal(tr, tt) and np.array_equal(r.view(np.uint32), tr_.view(np.uint32))
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,nbuf,steps", [(0, 4, 75), (1, 5, 83), (0, 48, 100)])
 def test_step_many_graph_replay_is_bit_identical(gymrs, twin, kind, nbuf, steps):
     """use_graph=1 replays captured graphs of >=32 steps with a device-resident tick; the result (state,

@@ -228,12 +228,20 @@ def check_against_one_unsharded_twin(tmp_path, twin, out, world, n=3001, steps=7
     for k in out["timing"]["calibration_calls"]:  # bench's untimed calibration calls (the ring index restarts with every call)
         run(k)
     full.stats_clear()
-    for _ in range(reps + 1):  # a repetition is ONE step_many call of passes * steps steps; one uncounted lead-in repetition
+    # a repetition is ONE step_many call of passes * steps steps; per call shape one uncounted lead-in repetition, and the second call
+    # shape (the chain, reported separately) starts with one untimed call of a repetition's length
+    assert set(out["paths"]) == {"per_step_visible", "chain"} and out["config"]["call_shape"] == "per_step_visible"
+    calls = 2 * (reps + 1) + 1
+    for _ in range(calls):
         run(steps * passes)
     want = full.stats()
     got = out["episodes"]
     assert (got["sum_return"], got["sum_length"], got["n_episodes"]) == (want[0], want[1], want[2])
-    assert want[3] == world * n * steps * passes * (reps + 1)
+    assert want[3] == world * n * steps * passes * calls
+    assert out["value"] == out["paths"]["per_step_visible"]["value"] and out["roofline"] == out["paths"]["per_step_visible"]["roofline"]
+    assert out["ranks_agree"] is True and out["expected_job_rate_from_rank_launch_times"] > 0
+    for r in out["ranks"]:
+        assert set(r["paths"]) == {"per_step_visible", "chain"}
     # shard invariance of the state itself: rank r's lanes are lanes [r*n, (r+1)*n) of the unsharded batch, bit for bit
     cat = np.concatenate([np.load(tmp_path / f"state{r}.npy") for r in range(world)], axis=1)
     assert np.array_equal(cat.view(np.uint32), full.get_state().view(np.uint32))

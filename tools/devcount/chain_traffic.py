@@ -57,7 +57,7 @@ def main():
     for b in range(args.nbuf):
         eng.fill_actions(ring.data_ptr() + b * args.n * esz, seed=1, t=b)
     eng.reset(seed=0)
-    eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, 2000)  # creates the chain object, calibrates the hand-over
+    eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, min(2000, args.steps))  # warm-up
     eng.sync()
     src = torch.ones(1 << 28, dtype=torch.float32, device=dev)
     dst = torch.empty_like(src)
@@ -87,7 +87,7 @@ def main():
     n_copies = 20
     phase("copy", lambda: [dst.copy_(src) for _ in range(n_copies)], n_copies)
     os.environ["GYMRS_AQL"] = "0"
-    phase("hip", lambda: eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, args.steps // 4), args.steps // 4)
+    phase("hip", lambda: eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, args.steps), args.steps)
     os.environ["GYMRS_AQL"] = "1"
     phase("chain", lambda: eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, args.steps), args.steps)
     phase("chain_again", lambda: eng.step_many(ring.data_ptr(), args.n * esz, args.nbuf, args.steps), args.steps)

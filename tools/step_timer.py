@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--flags", type=int, default=-1)
     ap.add_argument("--vec", type=int, default=4)
     ap.add_argument("--nt", type=int, default=0)
+    ap.add_argument("--nts", default="", help="comma-separated memory hints: one engine per (library, hint), timed alternately")
     ap.add_argument("--graph", type=int, default=0)
     ap.add_argument("--engine-first", type=int, default=0, help="create the engines before the action ring is allocated")
     ap.add_argument("--ring-2d", type=int, default=0)
@@ -66,6 +67,9 @@ def main():
         ring = torch.empty(nbuf * args.n * esz, dtype=torch.uint8, device="cuda:0")
     engines = []
     handles = []
+    nts = [int(x) for x in args.nts.split(",") if x] or [args.nt]
+    libs = [lb for lb in libs for _ in nts]
+    modes = [nt for _ in range(len(libs) // len(nts)) for nt in nts]
     for lb in libs:
         h = C.c_void_p()
         lb.ck(lb.lib.gymrs_engine_create(args.env, args.n, 0, 0, None, flags, C.byref(h)))
@@ -74,8 +78,8 @@ def main():
         ring = torch.empty(nbuf * args.n * esz, dtype=torch.uint8, device="cuda:0")
         torch.cuda.synchronize()
     print("ring at", hex(ring.data_ptr()), flush=True)
-    for lb, h in zip(libs, handles):
-        lb.ck(lb.lib.gymrs_set_tuning(h, args.vec, args.nt))
+    for lb, h, nt in zip(libs, handles, modes):
+        lb.ck(lb.lib.gymrs_set_tuning(h, args.vec, nt))
         lb.ck(lb.lib.gymrs_reset(h, 1, 0, None, None))
         for b in range(nbuf):
             lb.ck(lb.lib.gymrs_fill_actions(h, ring.data_ptr() + b * args.n * esz, 1, b))
@@ -83,22 +87,23 @@ def main():
         s = C.c_void_p()
         lb.ck(lb.lib.gymrs_get_stream(h, C.byref(s)))
         engines.append((lb, h, torch.cuda.ExternalStream(s.value, device="cuda:0")))
-    times = {lb.path: [] for lb in libs}
-    host = {lb.path: [] for lb in libs}
+    keys = [f"{lb.path} nt={nt}" for lb, nt in zip(libs, modes)]
+    times = {k: [] for k in keys}
+    host = {k: [] for k in keys}
     for lb, h, st in engines:  # warm-up (clocks, caches)
-        lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, 2000, args.graph))
+        lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, min(2000, args.steps), args.graph))
         lb.ck(lb.lib.gymrs_sync(h))
     for _ in range(args.reps):
-        for lb, h, st in engines:
+        for key, (lb, h, st) in zip(keys, engines):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             w0 = time.perf_counter()
             lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, args.steps, args.graph))
-            host[lb.path].append((time.perf_counter() - w0) * 1e6 / args.steps)
+            host[key].append((time.perf_counter() - w0) * 1e6 / args.steps)
             e1.record(st)
             lb.ck(lb.lib.gymrs_sync(h))
             wall = (time.perf_counter() - w0) * 1e6 / args.steps
-            times[lb.path].append(wall if args.wall else e0.elapsed_time(e1) * 1e3 / args.steps)
+            times[key].append(wall if args.wall else e0.elapsed_time(e1) * 1e3 / args.steps)
     for p, ts in times.items():
         print(f"{statistics.median(ts):8.3f} us median  {min(ts):8.3f} min  {max(ts):8.3f} max   host enqueue {statistics.median(host[p]):6.3f} us/step   {p}", flush=True)
     if args.all:
