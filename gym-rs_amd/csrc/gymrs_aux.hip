@@ -390,14 +390,15 @@ hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, ui
 // gymrs_tile.h).  Two shapes: at a step's footprint a work-item moves 4 items like the step kernel's tiles; from 1.5 GiB per launch on
 // (the HBM figure: 1 GiB + 1 GiB) one item per work-item -- measured on MI355X (profiles/r04_hbm_probe.log): 6.61 TB/s against 6.24 for the 4-item
 // shape and 5.9-6.1 for every persistent grid-stride form; the guide's own float4 copy reads 6.29.
-template <bool NT, int ITEMS>
+template <bool NTL, bool NTS, int ITEMS>
 __global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* src, uint64_t n_read16, uint32_t* dst,
                                                             uint64_t n_write16)
 {
-    copy_probe_body<NT, ITEMS>(src, n_read16, dst, n_write16);
+    copy_probe_body<NTL, NTS, ITEMS>(src, n_read16, dst, n_write16);
 }
 
-hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream)
+// hint: 0 none, 1 loads and stores non-temporal, 2 stores only
+hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, hipStream_t stream)
 {
     const uint64_t items = n_read16 > n_write16 ? n_read16 : n_write16;
     if (items == 0) return hipSuccess;
@@ -407,13 +408,16 @@ hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const uint32_t* s = static_cast<const uint32_t*>(src);
     uint32_t* d = static_cast<uint32_t*>(dst);
-    if (big) {
-        if (non_temporal) hipLaunchKernelGGL((copy_probe_kernel<true, 1>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
-        else hipLaunchKernelGGL((copy_probe_kernel<false, 1>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
-    } else {
-        if (non_temporal) hipLaunchKernelGGL((copy_probe_kernel<true, kCopyProbeItems>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
-        else hipLaunchKernelGGL((copy_probe_kernel<false, kCopyProbeItems>), dim3((uint32_t)grid), dim3(kBlock), 0, stream, s, n_read16, d, n_write16);
-    }
+    const dim3 g((uint32_t)grid), b(kBlock);
+#define GYMRS_COPY_LAUNCH(NTL_, NTS_)                                                                                                  \
+    do {                                                                                                                               \
+        if (big) hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, 1>), g, b, 0, stream, s, n_read16, d, n_write16);                   \
+        else hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, kCopyProbeItems>), g, b, 0, stream, s, n_read16, d, n_write16);         \
+    } while (0)
+    if (hint == 1) GYMRS_COPY_LAUNCH(true, true);
+    else if (hint == 2) GYMRS_COPY_LAUNCH(false, true);
+    else GYMRS_COPY_LAUNCH(false, false);
+#undef GYMRS_COPY_LAUNCH
     return hipGetLastError();
 }
 

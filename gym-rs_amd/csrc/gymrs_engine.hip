@@ -1301,7 +1301,8 @@ static uint32_t chain_hint_bits(const gymrs_engine* e)
     if (e->nt_mode == 2) return 0u;
     if (e->nt_mode == 3) return kFlagNtOut;
     const uint64_t per_step = bytes_per_step(e);
-    if (per_step >= (340ull << 20)) return kFlagNonTemporal;
+    if (per_step >= (1024ull << 20)) return kFlagNonTemporal; // (round 4: outputs only up to 1 GiB per step, as for HIP launches -- CartPole 2^24
+                                                              // lanes 109 -> 101 us, MountainCar 2^24 50.7 -> 44.7; profiles/r04_hints_by_size.log)
     return per_step <= (48ull << 20) ? (kFlagNtOut | kFlagNtStateLoads) : kFlagNtOut;
 }
 
@@ -1348,7 +1349,7 @@ static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const Ste
         *err = "kernel-argument segment of the chain kernel is " + std::to_string(k.kernarg_bytes) + " bytes, the dispatcher fills " + std::to_string(sizeof(ka));
         return false;
     }
-    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err);
+    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads * kStepTiles) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err);
 }
 } // extern "C++"
 
@@ -1364,6 +1365,8 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     }
     // (test hook, tests/test_gpu_aql_chain.py: a table nobody's XCC matches -- and no recording launch -- stands in for a deal that changed
     // in mid-chain; the memset sits on the stream ahead of the hand-over into the chain)
+    const char* dev_no = std::getenv("GYMRS_DEV_NO_XCC_CHECK"); // (developer knob, A/B runs only: what the check costs)
+    const bool no_xcc_check = dev_no && dev_no[0] == '1';
     const char* wrong = std::getenv("GYMRS_AQL_TEST_WRONG_XCC");
     const bool poisoned = wrong && wrong[0] == '1';
     if (poisoned) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(aql_xcc_table(e->aql)), 0x11, 8, e->stream));
@@ -1409,6 +1412,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         a.xcc_table = aql_xcc_table(e->aql);
         a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
         e->chain_first = false;
+        if (no_xcc_check) a.xcc_check = 0u;
         bool ok = false;
         switch (e->kind) {
         case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err); break;
@@ -2232,12 +2236,13 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
                               double* us_per_launch)
 {
     if (!us_per_launch || launches == 0) return fail(GYMRS_EINVAL, "gymrs_copy_probe: NULL output or zero launches");
-    if (mode < 0 || mode > 3) return fail(GYMRS_EINVAL, "gymrs_copy_probe: mode must be 0 .. 3 (bit 0: non-temporal accesses, bit 1: through a chain)");
+    if (mode < 0 || mode > 7 || (mode & 5) == 5)
+        return fail(GYMRS_EINVAL, "gymrs_copy_probe: mode = hint (0 none, 1 loads and stores non-temporal, 4 stores only) | 2 for launches through a chain");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GYMRS_EHIP, "gymrs_copy_probe: no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(GYMRS_EINVAL, "gymrs_copy_probe: device index out of range");
     HIP_TRY(hipSetDevice(device));
-    const int non_temporal = mode & 1;
+    const int non_temporal = (mode & 1) ? 1 : ((mode & 4) ? 2 : 0); // launch_copy_probe's hint
     const bool chained = (mode & 2) != 0;
     const uint64_t n_read = read_bytes / 16, n_write = write_bytes / 16;
     const bool big = (n_read + n_write) * 16 >= kCopyProbeBigBytes;
@@ -2264,7 +2269,7 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
         // the same copy as launches of a CHAIN on a dispatcher queue of its own (acquire only, the release at the end of the chain): what a
         // chain's step has to be compared with -- the HIP-launched copy carries a release fence per launch, a chain's step does not
         chain = aql_create(device, &why);
-        if (!chain || !aql_kernel(chain, non_temporal ? "gymrs_aql_copy_probe_nt" : "gymrs_aql_copy_probe_pl", &k)) chain_failed = true;
+        if (!chain || !aql_kernel(chain, non_temporal == 1 ? "gymrs_aql_copy_probe_nt" : (non_temporal == 2 ? "gymrs_aql_copy_probe_st" : "gymrs_aql_copy_probe_pl"), &k)) chain_failed = true;
         if (!chain_failed) (void)aql_calibrate(chain, stream, true);
     }
     auto run = [&](uint32_t count) -> hipError_t {

@@ -129,6 +129,14 @@ inline int step_threads_of(gymrs_env_kind kind, uint64_t n, int vec)
     return (kind == GYMRS_CARTPOLE && n >= (uint64_t)kCartPoleThreads * vec * kBigGroupsFrom) ? kCartPoleThreads : kBlock;
 }
 
+// Tiles (of `threads` * `vec` lanes) a workgroup of the per-step kernel steps one after the other: 1; developer builds (GYMRS_EXP_TILES,
+// tools/devbuild.py) may ask for more (profiles/r04_two_tiles_per_workgroup.log).
+#ifdef GYMRS_EXP_TILES
+constexpr int kStepTiles = GYMRS_EXP_TILES;
+#else
+constexpr int kStepTiles = 1;
+#endif
+
 // Number of workgroups of `threads` work-items for n lanes at `vec` lanes per work-item (4 or 8).
 inline uint32_t step_grid(uint64_t n, int vec, int threads = kBlock)
 {

@@ -73,7 +73,7 @@ __device__ __forceinline__ void rollout_block(StepArgs a, const RolloutArgs& r, 
             a.truncate_all = (a.tick + 1 - ustart >= c.max_steps) ? 1u : 0u;
             if (a.truncate_all && R::AUTO) ustart = a.tick + 1;
         }
-        advance_tile<Env, VEC, FLAGS, FULL, true, kBlock>(a, c, base, d, lds, resets, ret, open, out);
+        advance_tile<Env, VEC, FLAGS, FULL, true, kBlock>(a, c, base, d, lds, resets, ret, open, out, blockIdx.x);
         if constexpr (REC) {
             const uint64_t row = (uint64_t)k * r.rec_stride;
             constexpr int kObs = Env::kHasObsExtra ? 3 : Env::kState;

@@ -39,14 +39,14 @@ GYMRS_AQL_STEP_FLAGSETS(mountain_car, MountainCarT, 256)
 GYMRS_AQL_STEP_FLAGSETS(pendulum, PendulumT, 256)
 
 // ---- the copy probe's kernel (gymrs_copy_probe through a chain: the floor a chain's step is compared with) ---------------------
-extern "C" __global__ __launch_bounds__(kBlock) void gymrs_aql_copy_probe_pl(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)
-{
-    copy_probe_body<false, kCopyProbeItems>(src, n_read16, dst, n_write16);
-}
-extern "C" __global__ __launch_bounds__(kBlock) void gymrs_aql_copy_probe_nt(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)
-{
-    copy_probe_body<true, kCopyProbeItems>(src, n_read16, dst, n_write16);
-}
+#define GYMRS_AQL_COPY(NAME_, NTL_, NTS_)                                                                                                       \
+    extern "C" __global__ __launch_bounds__(kBlock) void NAME_(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)       \
+    {                                                                                                                                         \
+        copy_probe_body<NTL_, NTS_, kCopyProbeItems>(src, n_read16, dst, n_write16);                                                          \
+    }
+GYMRS_AQL_COPY(gymrs_aql_copy_probe_pl, false, false) // hints: none
+GYMRS_AQL_COPY(gymrs_aql_copy_probe_nt, true, true)   // loads and stores
+GYMRS_AQL_COPY(gymrs_aql_copy_probe_st, false, true)  // stores only
 
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put

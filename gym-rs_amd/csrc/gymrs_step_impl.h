@@ -60,21 +60,32 @@ __device__ __forceinline__ uint32_t select_by_mask(unsigned long long m, uint32_
 // 6.66 us (scattered stores, round 1) -> 6.47 us on the same box.  The folding launch is the SAME kernel taking a
 // wave-uniform branch on a kernel argument, not a second instantiation: alternating two kernels (each with its own copy of
 // the physics and reset code) cost MountainCar's 4 us launches up to 1.3 us each.
+// vblock = the index of the workgroup-sized tile (THREADS * VEC lanes): blockIdx.x, unless the workgroup steps several tiles
+// (step_kernel_body, TILES > 1).  `d` holds the tile's loads (issued, not necessarily landed).
 template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
-__device__ __forceinline__ void step_block(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds)
+__device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds, uint32_t vblock,
+                                                  TileRegs<Env, VEC, FLAGS>& d, uint32_t& xcc_want, uint32_t& xcc_id)
 {
     constexpr int kVec = VEC;
     constexpr int LPB = THREADS * kVec;
     constexpr bool AUTO = (FLAGS & GYMRS_AUTO_RESET) != 0;
     constexpr bool STATS = AUTO && (FLAGS & GYMRS_TRACK_STATS);
     constexpr bool LOGGED = TileRegs<Env, VEC, FLAGS>::LOGGED; // bookkeeping through the reset log: no statistics slot to load
-    const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * kVec;
-    GYMRS_STAMP(0);
-    TileRegs<Env, VEC, FLAGS> d;
-    load_tile<Env, VEC, FLAGS, FULL>(a, base, d);
+    const uint64_t base = (uint64_t)vblock * LPB + (uint64_t)threadIdx.x * kVec;
     // A replayed HIP graph keeps the tick on the device.  Resolved here, BEHIND the state loads: ahead of them
     // the branch makes every wave wait for the whole kernel-argument fetch before it issues its first load.
     if (a.tick_base) a.tick += *a.tick_base;
+    // (chains only, StepArgs::xcc_table) what the first launch of this chain recorded for this workgroup index: a scalar load, fetched
+    // BEHIND the state loads like everything else that is not a state load (ahead of them it cost the chain's step 0.35 us: every wave
+    // then waits for the tail of the kernel-argument fetch before it issues its first load), compared at the end of the kernel
+    if (a.xcc_check == 1u) xcc_want = a.xcc_table[blockIdx.x & 7u];
+    // ... and where this wavefront runs: s_getreg is a slow scalar instruction; here the wave waits for its loads anyway (issued at the very
+    // end of the kernel it kept every wave resident longer: +0.25 us per 2^20-lane step)
+    if (a.xcc_check != 0u && xcc_id == 0u) {
+        uint32_t id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+        xcc_id = (id & 0xfu) + 1u;
+    }
     // Episode statistics: every wavefront owns one {finished episodes, sum of returns} slot.  The old value
     // is fetched right behind the state loads (after them, so that the slot pointer does not split the
     // kernel-argument fetch in two) and the updated value leaves with the wave's last stores: the hot
@@ -82,7 +93,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     // has exactly one writer per launch.)
     unsigned long long old_resets = 0;
     double old_ret = 0.0, open = 0.0;
-    const size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); // = the global wave index
+    const size_t wave_slot = (size_t)vblock * (THREADS / 64) + (threadIdx.x >> 6); // = the global wave index
     if (STATS && !LOGGED) {
         const unsigned long long* bs = a.block_stats + wave_slot * 2;
         old_resets = bs[0];
@@ -116,7 +127,7 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     if (ELIDE) clean = a.wave_clean[wave_slot];
     GYMRS_STAMP(1);
     StepOut<VEC> out;
-    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out);
+    advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out, vblock);
     store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
     if (fold) {
         const uint32_t lane = threadIdx.x & 63u;
@@ -148,6 +159,16 @@ __device__ __forceinline__ void step_block(StepArgs a, const typename Env::Const
     GYMRS_STAMP(6);
 }
 
+template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
+__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds, uint32_t vblock,
+                                           uint32_t& xcc_want, uint32_t& xcc_id)
+{
+    GYMRS_STAMP(0);
+    TileRegs<Env, VEC, FLAGS> d;
+    load_tile<Env, VEC, FLAGS, FULL>(a, (uint64_t)vblock * (THREADS * VEC) + (uint64_t)threadIdx.x * VEC, d);
+    step_block_loaded<Env, VEC, FLAGS, THREADS, FULL>(a, c, lds, vblock, d, xcc_want, xcc_id);
+}
+
 // VEC lanes per work-item: 4 (4096 waves for 2^20 lanes, 4 waves per SIMD) or 8 (2 waves per SIMD; a tuning knob: measured
 // 9.9 vs 6.8 us; 16 lanes, 28 us, were removed).  More lanes per wave = fewer waves = fewer per-wave fixed costs (address set-up, the
 // auto-reset Philox pass, which costs the same whether 11 or 45 of its 64 lanes are active) at the price of
@@ -173,24 +194,36 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
     // straddles n (and the empty ones behind it) takes the guarded per-lane code.  n_fast (a preloaded scalar
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
-    // (chains only, StepArgs::xcc_table) what the first launch of this chain recorded for this workgroup index: fetched here, a scalar
-    // load next to the kernel-argument fetch, compared after the stores have been issued
-    uint32_t xcc_want = 0;
-    if (rest.xcc_check == 1u) xcc_want = rest.xcc_table[blockIdx.x & 7u];
-    if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
-        step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds);
-    else
-        step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds);
+    uint32_t xcc_want = 0, xcc_id = 0; // (chains: both fetched inside step_block_loaded, behind the state loads)
+    if constexpr (kStepTiles == 1) {
+        if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
+            step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x, xcc_want, xcc_id);
+        else
+            step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x, xcc_want, xcc_id);
+    } else {
+        // (developer builds, GYMRS_EXP_TILES) a workgroup steps kStepTiles consecutive tiles, the loads of tile j + 1 issued before the
+        // arithmetic of tile j: more bytes in flight per resident wave where a launch is several generations of waves
+        const uint32_t vb0 = blockIdx.x * (uint32_t)kStepTiles;
+        if ((uint64_t)(vb0 + kStepTiles - 1) * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast) {
+            TileRegs<Env, VEC, FLAGS> d[2];
+            load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)vb0 * LPB + (uint64_t)threadIdx.x * VEC, d[0]);
+#pragma unroll
+            for (int j = 0; j < kStepTiles; ++j) {
+                if (j + 1 < kStepTiles) load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)(vb0 + j + 1) * LPB + (uint64_t)threadIdx.x * VEC, d[(j + 1) & 1]);
+                step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, vb0 + j, d[j & 1], xcc_want, xcc_id);
+            }
+        } else {
+            for (int j = 0; j < kStepTiles; ++j)
+                if ((uint64_t)(vb0 + j) * LPB < rest.n) step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, vb0 + j, xcc_want, xcc_id);
+        }
+    }
     // A launch of a chain: no release fence separates it from the next one, so this tile's lines must be found in THIS XCD's L2 by the
     // next launch's workgroup of the same index (gymrs_aql.h).  The premise is checked where it matters, in every production launch: a
     // handful of scalar instructions per wavefront (one s_getreg, one scalar load, a compare).
     if (rest.xcc_check != 0u) {
-        uint32_t id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        id = (id & 0xfu) + 1u;
         if (rest.xcc_check == 2u) { // first launch of the chain: workgroups 0 .. 7 write the table through (agent scope: `sc1`)
-            if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(&rest.xcc_table[blockIdx.x], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (xcc_want != 0u && xcc_want != id && (threadIdx.x & 63u) == 0) {
+            if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(&rest.xcc_table[blockIdx.x], xcc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (xcc_want != 0u && xcc_want != xcc_id && (threadIdx.x & 63u) == 0) {
             rest.err_seen[1] = blockIdx.x + 1u;
         }
     }
@@ -222,12 +255,12 @@ static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t 
 {
     if constexpr (Env::kThreads != kBlock) {
         if (a.n >= (uint64_t)Env::kThreads * VEC * kBigGroupsFrom) { // >= 2 big workgroups per CU
-            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads)), dim3(Env::kThreads), 0,
+            hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads * kStepTiles)), dim3(Env::kThreads), 0,
                                stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
+    hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, kBlock>), dim3(step_grid(a.n, VEC, kBlock * kStepTiles)), dim3(kBlock), 0, stream, a.s[0], a.s[1],
                        a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
     return hipGetLastError();
 }

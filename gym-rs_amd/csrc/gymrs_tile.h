@@ -113,7 +113,7 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint
 // The copy probe's kernel body (gymrs_copy_probe; launched through HIP from gymrs_aux.hip and, as gymrs_aql_copy_probe_*, through the
 // engine's own dispatcher): a work-item moves ITEMS 16-byte items, its loads all in flight before its first store; a workgroup a
 // contiguous chunk of 256 * ITEMS items.
-template <bool NT, int ITEMS>
+template <bool NTL, bool NTS, int ITEMS>
 __device__ __forceinline__ void copy_probe_body(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16) // (src and dst may alias: in place)
 {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -123,13 +123,13 @@ __device__ __forceinline__ void copy_probe_body(const uint32_t* src, uint64_t n_
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t i = first + (uint64_t)j * kBlock;
         v[j] = u4{(uint32_t)i, 1u, 2u, 3u};
-        if (i < n_read16) v[j] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i) : reinterpret_cast<const u4*>(src)[i];
+        if (i < n_read16) v[j] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i) : reinterpret_cast<const u4*>(src)[i];
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint64_t i = first + (uint64_t)j * kBlock;
         if (i < n_write16) {
-            if (NT)
+            if (NTS)
                 __builtin_nontemporal_store(v[j], reinterpret_cast<u4*>(dst) + i);
             else
                 reinterpret_cast<u4*>(dst)[i] = v[j];
@@ -370,10 +370,11 @@ struct StepOut {
 // finished episodes of a wave is just that sum -- no per-lane return accumulator in HBM (which cost 8 B per
 // lane-step: 29.6 vs 23.4 us per 2^22-lane step).  The caller loads/stores `open` (StepArgs::wave_open).
 // a.fold_step: a folding launch of a reset-logged per-step kernel (step_block): the step's done-masks stay in registers.
+// vblock: the index of the workgroup-sized tile (THREADS * VEC lanes) this is -- blockIdx.x, unless a workgroup steps several tiles.
 template <class Env, int VEC, uint32_t FLAGS, bool FULL, bool ROLL = false, int THREADS = Env::kThreads>
 __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename Env::Consts& c, uint64_t base,
                                              TileRegs<Env, VEC, FLAGS>& d, ResetLds<Env, VEC, THREADS>& lds, unsigned long long& resets,
-                                             double& ret, double& open, StepOut<VEC>& out)
+                                             double& ret, double& open, StepOut<VEC>& out, uint32_t vblock)
 {
     static_assert(Env::kConstReward || Env::kNeverTerminates,
                   "return tracking assumes a constant reward (return = +-length) or one shared episode clock");
@@ -503,7 +504,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
                 // 2^20 CartPole lanes: the scattered ep_start stores cost 0.45 us per launch -- ~47k partial cache lines -- and the
                 // counter's load + store 0.07; this row entry costs 0.02.)  A folding launch consumes its masks from registers.
                 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-                const size_t wave_slot = (size_t)blockIdx.x * (THREADS / 64) + wave;
+                const size_t wave_slot = (size_t)vblock * (THREADS / 64) + wave;
                 ull2* row = reinterpret_cast<ull2*>(a.reset_log + (size_t)((uint32_t)a.tick & (kResetLogRows - 1u)) * a.reset_log_row_words +
                                                     wave_slot * kVec);
 #pragma unroll
@@ -538,7 +539,7 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
                 }
             }
             if (STATS && !LOGGED) { // the wave's private statistics slot: plain read-modify-write, no atomics
-                unsigned long long* bs = a.block_stats + ((size_t)blockIdx.x * (THREADS / 64) + wave) * 2;
+                unsigned long long* bs = a.block_stats + ((size_t)vblock * (THREADS / 64) + wave) * 2;
                 if (!Env::kConstReward) { // every lane of the wave finished (shared clock): the open sum is their return
                     ret += open;
                     open = 0.0;
