@@ -380,52 +380,47 @@ def load_pmc(name: str, env: str, sha: str):
 
 
 def measure_pmc_traffic(args, env_name: str, sha: str):
-    """Short rocprofv3 --pmc passes of this very command (one counter per pass, counters only), read back from the rocpd databases;
-    FETCH_SIZE doubled as the guide's gfx950 correction for wide coalesced reads prescribes.  Two submission paths, two passes each:
-      * "chain": the chain's own kernel.  rocprofv3's counter collection serialises kernels across queues, so the chains run with the
-        SYNCHRONOUS hand-over there (GYMRS_AQL_SYNC=1: no kernel of the stream in flight next to the chain) -- and what the profiler
-        does between two serialised kernels is outside the kernel's counter window: lines the kernel leaves dirty in the L2s (its state
-        stores, by design) are not in its WRITE_SIZE;
-      * "hip": the same code launched through HIP (GYMRS_AQL=0), every access hinted, a release fence inside every launch's window."""
+    """PER-DISPATCH counters of this very command: two short rocprofv3 --pmc passes (one counter per pass, counters only), read back from the
+    rocpd databases; FETCH_SIZE doubled as the guide's gfx950 correction for wide coalesced reads prescribes.  Both call shapes run in each
+    pass (the HIP-launched kernel and the chain's copy of it are told apart by name).  rocprofv3's counter collection serialises kernels
+    across queues, so the chains use the SYNCHRONOUS hand-over there (GYMRS_AQL_SYNC=1), and what the profiler does between two serialised
+    kernels lies outside a kernel's counter window: these figures describe a kernel run IN ISOLATION (every launch finds the caches as the
+    profiler left them), not the free-running launches the bench times -- those are in profiles/devcount_traffic.json."""
     import sqlite3
     import subprocess
     import tempfile
 
-    recs = {}
+    out = {}
     note = None
     with tempfile.TemporaryDirectory(prefix="gymrs_pmc_", dir="/tmp") as tmp:
-        for path_name, path_env in (("chain", {"GYMRS_AQL": "1", "GYMRS_AQL_SYNC": "1"}), ("hip", {"GYMRS_AQL": "0"})):
-            out = {}
-            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                d = Path(tmp) / f"{path_name}_{ctr}"
-                cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
-                       "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
-                if args.n_envs:
-                    cmd += ["--n-envs", str(args.n_envs)]
-                if args.vec:
-                    cmd += ["--vec", str(args.vec)]
-                env = dict(os.environ, TMPDIR="/tmp", **path_env)
-                res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
-                dbs = list(d.rglob("*_results.db"))
-                if res.returncode != 0 or not dbs:
-                    return None, f"rocprofv3 --pmc {ctr} ({path_name}) failed (rc {res.returncode}): {res.stderr[-300:]}"
-                c = sqlite3.connect(str(dbs[0]))
-                glob = f"gymrs_aql_{env_name}_f[0-9]_t*" if path_name == "chain" else "*step_kernel*"  # (GLOB: `_` is a wildcard of LIKE)
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = Path(tmp) / ctr
+            cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
+                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
+            if args.n_envs:
+                cmd += ["--n-envs", str(args.n_envs)]
+            if args.vec:
+                cmd += ["--vec", str(args.vec)]
+            env = dict(os.environ, TMPDIR="/tmp", GYMRS_AQL_SYNC="1")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=900)
+            dbs = list(d.rglob("*_results.db"))
+            if res.returncode != 0 or not dbs:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {res.returncode}): {res.stderr[-300:]}"
+            c = sqlite3.connect(str(dbs[0]))
+            for path_name, glob in (("chain", f"gymrs_aql_{env_name}_f[0-9]_t*"), ("per_step_visible", "*step_kernel*")):  # (GLOB: `_` is a wildcard of LIKE)
                 r = c.execute("select count(*), avg(value) from counters_collection where kernel_name glob ? and counter_name = ?", (glob, ctr)).fetchone()
-                out[ctr] = {"launches": r[0], "avg_kb": r[1]}
-            if not out["FETCH_SIZE"]["launches"] or not out["WRITE_SIZE"]["launches"]:
-                continue  # (that path did not run under the profiler: e.g. no chains on this box)
-            fetch = 2.0 * out["FETCH_SIZE"]["avg_kb"] * 1024.0
-            write = out["WRITE_SIZE"]["avg_kb"] * 1024.0
-            recs[path_name] = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "raw": out}
-    if "hip" not in recs:
+                out.setdefault(path_name, {})[ctr] = {"launches": r[0], "avg_kb": r[1]}
+    recs = {}
+    for path_name, o in out.items():
+        if not o["FETCH_SIZE"]["launches"] or not o["WRITE_SIZE"]["launches"]:
+            continue  # (that call shape did not run under the profiler: e.g. no chains on this box)
+        fetch = 2.0 * o["FETCH_SIZE"]["avg_kb"] * 1024.0
+        write = o["WRITE_SIZE"]["avg_kb"] * 1024.0
+        recs[path_name] = {"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write, "raw": o}
+    if not recs:
         return None, "rocprofv3 --pmc: no launch of the step kernel was counted"
-    rec = dict(recs["hip"])  # (top level = the HIP-launched kernel, as in rounds 1-2)
-    rec["correction"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported"
-    if "chain" in recs:
-        rec["chain"] = recs["chain"]
-        rec["chain"]["note"] = ("the chain's own kernel, counted under rocprofv3's serialisation with the synchronous hand-over; lines still dirty in the "
-                                "L2s when the kernel ends (its state stores) are written back outside its counter window")
+    recs["correction"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests of wide coalesced reads as 64 B); WRITE_SIZE as reported"
+    recs["what"] = "per-dispatch counters under rocprofv3's serialisation: each kernel in isolation, not free-running launches"
     path = ROOT / "profiles" / "pmc_traffic.json"
     try:
         data = json.loads(path.read_text())
@@ -434,12 +429,12 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
     except Exception:
         data = {}
     data["kernel_source_sha16"] = sha
-    data[env_name] = rec
+    data[env_name] = recs
     try:
         path.write_text(json.dumps(data, indent=1))
     except Exception as exc:  # read-only checkout: the figure is still reported
         note = f"could not refresh profiles/pmc_traffic.json: {exc}"
-    return rec, note
+    return recs, note
 
 
 def run_rank(args, info, backend, make_collective=None):
@@ -663,6 +658,16 @@ def run_rank(args, info, backend, make_collective=None):
         if per_step:
             out["roofline"] = hd["roofline"]
             out["paths"] = path_out
+            # per-dispatch PMC figures next to the free-running ones: measured by this run (--pmc-traffic) or the committed file if it
+            # belongs to these kernels
+            pmc, pnote = (measure_pmc_traffic(args, args.env, sha) if (args.pmc_traffic and info.world == 1 and backend.name == "hip")
+                          else load_pmc("pmc_traffic.json", args.env, sha))
+            for path, prec in path_out.items():
+                if pmc and pmc.get(path) and config_name:
+                    prec["roofline"]["traffic_per_dispatch_pmc"] = {k: pmc[path][k] for k in ("bytes_per_launch", "fetch_bytes", "write_bytes")}
+                    prec["roofline"]["traffic_per_dispatch_pmc"]["what"] = pmc.get("what", "rocprofv3 --pmc, per dispatch")
+                elif pnote and args.pmc_traffic:
+                    prec["roofline"]["traffic_per_dispatch_pmc_note"] = pnote
             if "chain" in path_out and head != "chain":
                 out["paths"]["chain"]["reported_separately"] = ("not the headline: inside a chain nobody can read a step's observation / reward / done before "
                                                                 "the chain ends (SURVEY H1: report multi-step variants separately)")

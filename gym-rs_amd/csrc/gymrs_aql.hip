@@ -2,6 +2,7 @@
 // HSA next to HIP: the HIP runtime sits on the same ROCr instance, hsa_init() only takes a reference; device memory that
 // hipMalloc returned is ordinary agent memory to a kernel dispatched through an HSA queue of the same agent.
 #include "gymrs_aql.h"
+#include "gymrs_kernels.h"
 
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
@@ -191,8 +192,8 @@ public:
     uint32_t calibrated_epoch = 0;
     bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
-    // [8] device words the first step launch of every chain records the XCC of its workgroups 0 .. 7 in and the later launches of that
-    // chain compare against (StepArgs::xcc_table)
+    // 8 entries (one cache line each) the first step launch of every chain records {chain number, XCC} of its workgroups 0 .. 7 in and the
+    // later launches of that chain compare against (StepArgs::xcc_table)
     uint32_t* xcc_table = nullptr;
     unsigned long long wait_ticks = 10ull * 100000000ull; // bound of the chain's first packet (100 MHz ticks)
     std::atomic<int> queue_status{0};
@@ -538,7 +539,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
     if (ok) ok = hsa_signal_create(1, 0, nullptr, &ch->done) == HSA_STATUS_SUCCESS;
     if (ok) {
         void* p = nullptr;
-        ok = hipMalloc(&p, 64) == hipSuccess && hipMemset(p, 0, 64) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+        ok = hipMalloc(&p, 8 * kXccTableStride * 4) == hipSuccess && hipMemset(p, 0, 8 * kXccTableStride * 4) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
         ch->xcc_table = static_cast<uint32_t*>(p);
         if (!ok) *why = "hipMalloc (XCD table) failed";
     }

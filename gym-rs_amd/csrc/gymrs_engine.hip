@@ -1369,7 +1369,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     const bool no_xcc_check = dev_no && dev_no[0] == '1';
     const char* wrong = std::getenv("GYMRS_AQL_TEST_WRONG_XCC");
     const bool poisoned = wrong && wrong[0] == '1';
-    if (poisoned) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(aql_xcc_table(e->aql)), 0x11, 8, e->stream));
+    if (poisoned) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(aql_xcc_table(e->aql)), 0x11, 8 * kXccTableStride, e->stream));
     if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched, no host state touched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
         aql_destroy(e->aql);
@@ -1411,6 +1411,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         // every wavefront of a chain launch checks where it runs; the chain's first launch records the table (StepArgs::xcc_table)
         a.xcc_table = aql_xcc_table(e->aql);
         a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
+        a.xcc_seq = (uint32_t)((e->aql_chains + 1) & 0xffffffu); // (aql_chains counts the CLOSED chains: constant while this one is open)
         e->chain_first = false;
         if (no_xcc_check) a.xcc_check = 0u;
         bool ok = false;

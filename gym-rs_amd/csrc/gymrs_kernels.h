@@ -60,12 +60,14 @@ struct StepArgs {
     // Launches of a chain (gymrs_aql.h) carry no release fence between them, which is only right while tile i is stepped on the SAME
     // XCD (= the same L2) in every launch of the chain.  Where a queue's workgroups start is NOT a constant of the queue (round 4: it
     // differs between queues and changes while a queue sits idle), so the premise is checked per chain: the FIRST step launch after
-    // aql_begin (xcc_check == 2) records the XCC of its workgroups 0 .. 7 in xcc_table (written through: `sc1`), every later launch of
-    // the chain (xcc_check == 1) compares the XCC it runs on (HW_REG_XCC_ID) with entry (blockIdx.x & 7) and reports a mismatch through
-    // err_seen[1].  Between two chains everything is written back and re-acquired, so a deal that changed THERE is harmless.  HIP
-    // launches (a release fence each) pass xcc_check == 0.
-    uint32_t* xcc_table; // [8] device words: XCC id + 1 (0 = not recorded: fewer than 8 workgroups)
+    // aql_begin (xcc_check == 2) has its workgroups 0 .. 7 store {chain number, XCC id} into xcc_table (entry k at word k * kXccTableStride:
+    // one cache line each; a plain store, which stays in that XCD's L2), every later launch of the chain (xcc_check == 1) compares the
+    // XCC it runs on (HW_REG_XCC_ID) and the chain number with entry (blockIdx.x & 7) and reports a mismatch through err_seen[1]: a
+    // workgroup on the wrong XCD does not see the entry at all (it reads an older chain's).  Between two chains everything is written back and
+    // re-acquired, so a deal that changed THERE is harmless.  HIP launches (a release fence each) pass xcc_check == 0.
+    uint32_t* xcc_table; // [8 * kXccTableStride] device words
     uint32_t xcc_check;
+    uint32_t xcc_seq;    // the chain's number (24 bits)
     uint32_t trace_wpb; // wavefronts per workgroup of this launch (the stamps' index; blockDim would be a hidden kernel argument, which
                         // the engine's own dispatcher does not supply)
 };
@@ -128,6 +130,8 @@ inline int step_threads_of(gymrs_env_kind kind, uint64_t n, int vec)
 {
     return (kind == GYMRS_CARTPOLE && n >= (uint64_t)kCartPoleThreads * vec * kBigGroupsFrom) ? kCartPoleThreads : kBlock;
 }
+
+constexpr uint32_t kXccTableStride = 32; // words between two entries of StepArgs::xcc_table: one 128-byte line per entry
 
 // Tiles (of `threads` * `vec` lanes) a workgroup of the per-step kernel steps one after the other: 1; developer builds (GYMRS_EXP_TILES,
 // tools/devbuild.py) may ask for more (profiles/r04_two_tiles_per_workgroup.log).

@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t select_by_mask(unsigned long long m, uint32_
 // (step_kernel_body, TILES > 1).  `d` holds the tile's loads (issued, not necessarily landed).
 template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
 __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds, uint32_t vblock,
-                                                  TileRegs<Env, VEC, FLAGS>& d, uint32_t& xcc_want, uint32_t& xcc_id)
+                                                  TileRegs<Env, VEC, FLAGS>& d)
 {
     constexpr int kVec = VEC;
     constexpr int LPB = THREADS * kVec;
@@ -75,17 +75,6 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
     // A replayed HIP graph keeps the tick on the device.  Resolved here, BEHIND the state loads: ahead of them
     // the branch makes every wave wait for the whole kernel-argument fetch before it issues its first load.
     if (a.tick_base) a.tick += *a.tick_base;
-    // (chains only, StepArgs::xcc_table) what the first launch of this chain recorded for this workgroup index: a scalar load, fetched
-    // BEHIND the state loads like everything else that is not a state load (ahead of them it cost the chain's step 0.35 us: every wave
-    // then waits for the tail of the kernel-argument fetch before it issues its first load), compared at the end of the kernel
-    if (a.xcc_check == 1u) xcc_want = a.xcc_table[blockIdx.x & 7u];
-    // ... and where this wavefront runs: s_getreg is a slow scalar instruction; here the wave waits for its loads anyway (issued at the very
-    // end of the kernel it kept every wave resident longer: +0.25 us per 2^20-lane step)
-    if (a.xcc_check != 0u && xcc_id == 0u) {
-        uint32_t id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
-        xcc_id = (id & 0xfu) + 1u;
-    }
     // Episode statistics: every wavefront owns one {finished episodes, sum of returns} slot.  The old value
     // is fetched right behind the state loads (after them, so that the slot pointer does not split the
     // kernel-argument fetch in two) and the updated value leaves with the wave's last stores: the hot
@@ -125,6 +114,26 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
     constexpr bool ELIDE = AUTO && Env::kConstReward && Env::kElideConstReward;
     uint32_t clean = 0;
     if (ELIDE) clean = a.wave_clean[wave_slot];
+    // Chains only (StepArgs::xcc_table): is this workgroup index still on the XCD the chain's first launch found its residue class (mod 8) on?
+    // One wavefront per workgroup asks.  The table entry was stored PLAINLY by a workgroup of that first launch, so while the deal is
+    // stable it is read out of this XCD's own L2 like the state (a table written through by another XCD took ~1 us to arrive and cost
+    // MountainCar's 3.1 us chain step 0.3 us: profiles/r04_xcd_check_cost.log); a workgroup that finds itself elsewhere reads whatever memory
+    // holds -- an older chain's tag -- and reports.  Both reads sit HERE, behind every load of the step: the wave waits for memory anyway
+    // (s_getreg is a slow scalar instruction; at the end of the kernel it kept every wave resident 0.25 us longer).
+#ifndef GYMRS_EXP_XCC_PARTS // (developer builds, A/B runs: 1 the table fetch, 2 the s_getreg, 4 the compare / record at the end; 0 = no check)
+#define GYMRS_EXP_XCC_PARTS 7
+#endif
+    uint32_t xcc_want = 0, xcc_id = 0;
+    const bool xcc_asks = a.xcc_check != 0u && (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x) < 64u && vblock == blockIdx.x * (uint32_t)kStepTiles;
+#if GYMRS_EXP_XCC_PARTS & 1
+    if (xcc_asks && a.xcc_check == 1u) xcc_want = a.xcc_table[(blockIdx.x & 7u) * kXccTableStride];
+#endif
+#if GYMRS_EXP_XCC_PARTS & 2
+    if (xcc_asks) {
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        xcc_id = (a.xcc_seq << 8) | ((xcc_id & 0xfu) + 1u); // tagged with the chain's number: an entry of an earlier chain never matches
+    }
+#endif
     GYMRS_STAMP(1);
     StepOut<VEC> out;
     advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out, vblock);
@@ -156,17 +165,25 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
     }
     if (ELIDE && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
     if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
+#if GYMRS_EXP_XCC_PARTS & 4
+    if (xcc_asks) { // (see above) the first launch of a chain records, every later one compares
+        if (a.xcc_check == 2u) {
+            if (blockIdx.x < 8u && threadIdx.x == 0) a.xcc_table[blockIdx.x * kXccTableStride] = xcc_id; // (plain: stays in this XCD's L2)
+        } else if (xcc_want != xcc_id && threadIdx.x == 0) {
+            a.err_seen[1] = blockIdx.x + 1u;
+        }
+    }
+#endif
     GYMRS_STAMP(6);
 }
 
 template <class Env, int VEC, uint32_t FLAGS, int THREADS, bool FULL>
-__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds, uint32_t vblock,
-                                           uint32_t& xcc_want, uint32_t& xcc_id)
+__device__ __forceinline__ void step_block(const StepArgs& a, const typename Env::Consts& c, ResetLds<Env, VEC, THREADS>& lds, uint32_t vblock)
 {
     GYMRS_STAMP(0);
     TileRegs<Env, VEC, FLAGS> d;
     load_tile<Env, VEC, FLAGS, FULL>(a, (uint64_t)vblock * (THREADS * VEC) + (uint64_t)threadIdx.x * VEC, d);
-    step_block_loaded<Env, VEC, FLAGS, THREADS, FULL>(a, c, lds, vblock, d, xcc_want, xcc_id);
+    step_block_loaded<Env, VEC, FLAGS, THREADS, FULL>(a, c, lds, vblock, d);
 }
 
 // VEC lanes per work-item: 4 (4096 waves for 2^20 lanes, 4 waves per SIMD) or 8 (2 waves per SIMD; a tuning knob: measured
@@ -194,12 +211,11 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
     // straddles n (and the empty ones behind it) takes the guarded per-lane code.  n_fast (a preloaded scalar
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
-    uint32_t xcc_want = 0, xcc_id = 0; // (chains: both fetched inside step_block_loaded, behind the state loads)
     if constexpr (kStepTiles == 1) {
         if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
-            step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x, xcc_want, xcc_id);
+            step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x);
         else
-            step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x, xcc_want, xcc_id);
+            step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x);
     } else {
         // (developer builds, GYMRS_EXP_TILES) a workgroup steps kStepTiles consecutive tiles, the loads of tile j + 1 issued before the
         // arithmetic of tile j: more bytes in flight per resident wave where a launch is several generations of waves
@@ -210,21 +226,11 @@ __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2
 #pragma unroll
             for (int j = 0; j < kStepTiles; ++j) {
                 if (j + 1 < kStepTiles) load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)(vb0 + j + 1) * LPB + (uint64_t)threadIdx.x * VEC, d[(j + 1) & 1]);
-                step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, vb0 + j, d[j & 1], xcc_want, xcc_id);
+                step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, vb0 + j, d[j & 1]);
             }
         } else {
             for (int j = 0; j < kStepTiles; ++j)
-                if ((uint64_t)(vb0 + j) * LPB < rest.n) step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, vb0 + j, xcc_want, xcc_id);
-        }
-    }
-    // A launch of a chain: no release fence separates it from the next one, so this tile's lines must be found in THIS XCD's L2 by the
-    // next launch's workgroup of the same index (gymrs_aql.h).  The premise is checked where it matters, in every production launch: a
-    // handful of scalar instructions per wavefront (one s_getreg, one scalar load, a compare).
-    if (rest.xcc_check != 0u) {
-        if (rest.xcc_check == 2u) { // first launch of the chain: workgroups 0 .. 7 write the table through (agent scope: `sc1`)
-            if (blockIdx.x < 8u && threadIdx.x == 0) __hip_atomic_store(&rest.xcc_table[blockIdx.x], xcc_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else if (xcc_want != 0u && xcc_want != xcc_id && (threadIdx.x & 63u) == 0) {
-            rest.err_seen[1] = blockIdx.x + 1u;
+                if ((uint64_t)(vb0 + j) * LPB < rest.n) step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, vb0 + j);
         }
     }
 }
