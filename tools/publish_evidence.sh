@@ -14,6 +14,7 @@ for f in $SRC/${TAG}_*; do
         kt_bench.json) out=${ROUND}_bench_cartpole_under_rocprof.json ;;
         kt_graph_bench.json) out=${ROUND}_bench_cartpole_graph_under_rocprof.json ;;
         pmc_traffic.json) out=pmc_traffic.json ;;
+        devcount_traffic.json) out=devcount_traffic.json ;;
         pmc_valu.json) out=pmc_valu.json ;;
         *) out=${ROUND}_$name ;;
     esac

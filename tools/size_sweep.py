@@ -8,6 +8,7 @@ Prints, per size: step us, algorithmic GB/s, copy-probe us at the same footprint
 import argparse
 import ctypes as C
 import importlib
+import os
 import sys
 from pathlib import Path
 
@@ -55,13 +56,14 @@ def main():
         del ring
         torch.cuda.empty_cache()
         out = []
-        for nt in (0, 1):
+        chained = 2 if os.environ.get("GYMRS_AQL", "1") != "0" else 0  # the copy is submitted the way the steps are (chains unless GYMRS_AQL=0)
+        for hint in (0, 1, 4):  # none | loads and stores | stores only
             us = C.c_double()
-            stt = lib.gymrs_copy_probe(0, n * rd // 16 * 16, n * wr // 16 * 16, max(20, steps // 4), nt, C.byref(us))
+            stt = lib.gymrs_copy_probe(0, n * rd // 16 * 16, n * wr // 16 * 16, max(20, steps // 4), hint | chained, C.byref(us))
             out.append(us.value if stt == 0 else float("nan"))
         gbps = n * (rd + wr) / (best * 1e-6) / 1e9
-        print(f"2^{lg:2d} lanes: step {best:9.2f} us  {gbps:7.1f} GB/s algorithmic ({gbps / 8000:.3f} of 8 TB/s)   copy plain {out[0]:9.2f} us  nt {out[1]:9.2f} us"
-              f"   step/copy {best / min(out):.3f}", flush=True)
+        print(f"2^{lg:2d} lanes: step {best:9.2f} us  {gbps:7.1f} GB/s algorithmic ({gbps / 8000:.3f} of 8 TB/s)   in-place copy, {'chain' if chained else 'HIP launches'}: "
+              f"plain {out[0]:8.2f}  hinted {out[1]:8.2f}  stores hinted {out[2]:8.2f} us   step/copy {best / min(out):.3f}", flush=True)
 
 
 if __name__ == "__main__":
