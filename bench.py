@@ -96,18 +96,6 @@ def kernel_source_sha16() -> str:
     return h.hexdigest()[:16]
 
 
-def kernel_name(env: str, vec: int, flags: int, n: int, submission):
-    """The dominant kernel as a trace shows it: HIP's template instance, or -- inside chains -- its copy in the stand-alone code
-    object (gymrs_step_aql.hip; same template, the hint variant the engine's chain_hint_bits picks for this size)."""
-    if not (submission and submission.startswith("AQL")):
-        return "step_kernel<%s, %d, flags=%d>" % (env, vec, flags)
-    state_dim = 4 if env == "cartpole" else 2
-    per_step = n * (state_dim * 8 + 10 + (8 if env == "pendulum" else 0))
-    hint = "_nt" if per_step >= (340 << 20) else ("_so" if per_step <= (48 << 20) else "_o")
-    threads = 512 if env == "cartpole" and n >= 512 * vec * 512 else 256
-    return "gymrs_aql_%s_f%d_t%d%s (= step_kernel_body<%s, %d, flags=%d> in the chain's code object)" % (env, flags & 7, threads, hint, env, vec, flags)
-
-
 class submission:
     """The call shape of the gymrs_step_many calls inside the block (PATHS): the library looks GYMRS_AQL up per call."""
 

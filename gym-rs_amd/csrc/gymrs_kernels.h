@@ -124,11 +124,17 @@ struct ResetArgs {
 // Work-items per workgroup of a per-step launch: CartPole uses 512 once the launch still puts two such workgroups on every
 // CU (measured 2 % faster there; small batches want many small workgroups), everything else kBlock.  launch_one
 // (gymrs_step_impl.h) and the engine's AQL dispatcher both go by this.
+// ... and only while the launch is at most two generations of waves: from 2^22 lanes on a CU refills better in units of 4 waves (round 4,
+// profiles/r04_wave_variants.log: 2^22 lanes 25.7 -> 24.8 us, 2^23 48.7 -> 47.4; 2^21 12.0 vs 12.2 the other way).
 constexpr int kCartPoleThreads = 512;
-constexpr uint64_t kBigGroupsFrom = 512;
+constexpr uint64_t kBigGroupsFrom = 512, kBigGroupsBelow = 2048;
+inline bool step_uses_big_groups(uint64_t n, int threads, int vec)
+{
+    return n >= (uint64_t)threads * vec * kBigGroupsFrom && n < (uint64_t)threads * vec * kBigGroupsBelow;
+}
 inline int step_threads_of(gymrs_env_kind kind, uint64_t n, int vec)
 {
-    return (kind == GYMRS_CARTPOLE && n >= (uint64_t)kCartPoleThreads * vec * kBigGroupsFrom) ? kCartPoleThreads : kBlock;
+    return (kind == GYMRS_CARTPOLE && step_uses_big_groups(n, kCartPoleThreads, vec)) ? kCartPoleThreads : kBlock;
 }
 
 constexpr uint32_t kXccTableStride = 32; // words between two entries of StepArgs::xcc_table: one 128-byte line per entry

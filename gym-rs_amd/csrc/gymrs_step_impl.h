@@ -260,7 +260,7 @@ template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
     if constexpr (Env::kThreads != kBlock) {
-        if (a.n >= (uint64_t)Env::kThreads * VEC * kBigGroupsFrom) { // >= 2 big workgroups per CU
+        if (step_uses_big_groups(a.n, Env::kThreads, VEC)) { // >= 2 big workgroups per CU, at most two generations of waves
             hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads * kStepTiles)), dim3(Env::kThreads), 0,
                                stream, a.s[0], a.s[1], a.s[2], a.s[3], a.action, a.n_fast, a, *static_cast<const typename Env::Consts*>(consts));
             return hipGetLastError();

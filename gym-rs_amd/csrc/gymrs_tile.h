@@ -480,6 +480,15 @@ __device__ __forceinline__ void advance_tile(const StepArgs& a, const typename E
         open += (double)wave_sum(rs);
     }
 
+#ifdef GYMRS_EXP_EARLY_OUT // (developer builds: the step's reward / done / truncated leave BEFORE the re-arm pass; profiles/r04_wave_variants.log)
+    if (!ROLL && !Env::kElideConstReward) {
+#pragma unroll
+        for (int k = 0; k < kVec; ++k) out.reward.v[k] = rw[k];
+        store_vec<float, kVec, R::POL_O>(a.reward, base, a.n, FULL, out.reward);
+        if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::POL_O>(a.done, base, a.n, FULL, out.done);
+        if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::POL_O>(a.truncated, base, a.n, FULL, out.trunc);
+    }
+#endif
     // ---- auto-reset: wave __ballot done-mask -> LDS-staged Philox, all inside one wavefront ----
     if (AUTO) {
         constexpr int LPW = 64 * kVec; // lanes per wavefront = capacity of a wave's LDS segment
@@ -569,11 +578,16 @@ __device__ __forceinline__ void store_tile(const StepArgs& a, uint64_t base, con
     constexpr bool AUTO = R::AUTO, STATS = R::STATS, TLIM = R::TLIM;
 #pragma unroll
     for (int j = 0; j < Env::kState; ++j) store_vec<float, kVec, R::POL_SS>(a.s[j], base, a.n, FULL, d.st[j]);
-    if (!skip_reward) store_vec<float, kVec, R::POL_O>(a.reward, base, a.n, FULL, out.reward);
+#ifdef GYMRS_EXP_EARLY_OUT
+    constexpr bool kOutStored = !ROLL && !Env::kElideConstReward; // (advance_tile stored them already)
+#else
+    constexpr bool kOutStored = false;
+#endif
+    if (!skip_reward && !kOutStored) store_vec<float, kVec, R::POL_O>(a.reward, base, a.n, FULL, out.reward);
     // An env that never terminates never changes `done` (reset() zeroed it), and its `truncated` flag is the same
     // for every lane: neither is rewritten while it already holds the right value (2 of Pendulum's 34 real bytes).
-    if (!Env::kNeverTerminates) store_vec<uint8_t, kVec, R::POL_O>(a.done, base, a.n, FULL, out.done);
-    if (TLIM && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::POL_O>(a.truncated, base, a.n, FULL, out.trunc);
+    if (!Env::kNeverTerminates && !kOutStored) store_vec<uint8_t, kVec, R::POL_O>(a.done, base, a.n, FULL, out.done);
+    if (TLIM && !kOutStored && !(Env::kNeverTerminates && a.skip_trunc_store)) store_vec<uint8_t, kVec, R::POL_O>(a.truncated, base, a.n, FULL, out.trunc);
     if (Env::kHasBeyond && !AUTO) store_vec<uint8_t, kVec, R::POL_SS>(a.beyond, base, a.n, FULL, d.beyond);
     if (ROLL && (STATS || TLIM)) store_vec<uint32_t, kVec, 0>(a.ep_start, base, a.n, FULL, d.ep_start);
     if (Env::kHasObsExtra) {

@@ -269,32 +269,55 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
             for flags in (0, 1, 3, 4, 5, 7):
                 for hint in ("nt", "o", "so", "pl"):
                     names.append(f"gymrs_aql_{env}_f{flags}_t{threads}_{hint}".encode())
-    assert len(names) == 99
+    names += [b"gymrs_aql_copy_probe_pl", b"gymrs_aql_copy_probe_nt", b"gymrs_aql_copy_probe_st"]  # gymrs_copy_probe through a chain
+    assert len(names) == 102
     for name in names:
         assert blob.count(name + b".kd") >= 1, name
+    # (which variant a launch used is reported by the engine itself: gymrs_env_json(...)["gymrs"]["last_launch"], bench.py's roofline.kernel)
+
+
+def test_bench_rooflines_are_fractions_of_the_bound_that_applies():
+    """bench.roofline_of (host logic): the per-step-visible shape is held to the HBM roofline by the contract's algorithmic bytes; a chain is held
+    to the L2s while the fabric sees less than 0.9 x the algorithmic bytes (or nothing is on file and the arrays are small), to HBM beyond; the traffic
+    figure, where on file, gives frac_moved next to the counted fraction."""
     import bench
 
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 20, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_so ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_o ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 24, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t512_nt ")
-    assert bench.kernel_name("cartpole", 4, 3, 1 << 16, "AQL chains: ...").startswith("gymrs_aql_cartpole_f3_t256_so ")
-    assert bench.kernel_name("pendulum", 4, 7, 1 << 22, "AQL chains: ...").startswith("gymrs_aql_pendulum_f7_t256_o ")
-    assert bench.kernel_name("mountain_car", 4, 3, 1 << 20, "HIP launches (...)") == "step_kernel<mountain_car, 4, flags=3>"
+    n, b = 1 << 20, 38
+    vis = bench.roofline_of("per_step_visible", n, b, 6.4, {"bytes_per_launch": 26.1e6, "fetch_bytes": 4.4e6, "write_bytes": 21.7e6}, None, "k", "sha")
+    assert vis["bound"] == "hbm" and vis["peak"] == 8000.0 and vis["frac"] == pytest.approx(n * b / 6.4e-6 / 1e9 / 8000.0) and vis["frac"] < 1.0
+    assert vis["traffic"] == 26.1e6 and vis["frac_moved"] == pytest.approx(26.1e6 / 6.4e-6 / 1e9 / 8000.0) and vis["hbm_bound"] is False and "frac_note" in vis
+    ch = bench.roofline_of("chain", n, b, 4.9, {"bytes_per_launch": 18.5e6}, None, "k", "sha")
+    assert ch["bound"] == "l2" and ch["peak"] == 34500.0 and 0 < ch["frac"] < 1.0 and "bound_note" in ch and "hbm_bound" not in ch
+    big = bench.roofline_of("chain", 1 << 24, b, 99.0, {"bytes_per_launch": 660e6}, None, "k", "sha")
+    assert big["bound"] == "hbm" and big["hbm_bound"] is True and big["frac"] < 1.0
+    nofile = bench.roofline_of("chain", n, b, 4.9, None, "why", "k", "sha")
+    assert nofile["bound"] == "l2" and nofile["traffic"] is None and nofile["traffic_note"] == "why"
+    assert bench.roofline_of("chain", 1 << 24, b, 99.0, None, "why", "k", "sha")["bound"] == "hbm"
 
 
-def test_committed_pmc_traffic_covers_both_submission_paths():
-    """profiles/pmc_traffic.json is what bench.py's roofline.traffic / traffic_chain_kernel quote.  When it belongs to the current
-    kernel sources it must hold, per env, the HIP-launched kernel's bytes AND the chain's own kernel's (a renamed kernel once made
-    the chain's record silently disappear from the file)."""
+def test_committed_traffic_files_cover_both_call_shapes():
+    """profiles/devcount_traffic.json (free-running launches, device-wide counters) is what bench.py's roofline.traffic quotes;
+    profiles/pmc_traffic.json the per-dispatch figures beside it.  When a file belongs to the current kernel sources it must hold both call
+    shapes (a renamed kernel once made the chain's record silently disappear)."""
     import json
     from pathlib import Path
 
     import bench
 
-    data = json.loads((Path(bench.ROOT) / "profiles" / "pmc_traffic.json").read_text())
-    if data.get("kernel_source_sha16") != bench.kernel_source_sha16():
-        pytest.skip("profiles/pmc_traffic.json belongs to other kernel sources (bench.py drops it as stale)")
-    for env in ("cartpole", "mountain_car", "pendulum"):
-        rec = data[env]
-        assert rec["bytes_per_launch"] > 0 and rec["chain"]["bytes_per_launch"] > 0, env
-        assert rec["raw"]["FETCH_SIZE"]["launches"] > 0 and rec["chain"]["raw"]["WRITE_SIZE"]["launches"] > 0, env
+    sha = bench.kernel_source_sha16()
+    checked = 0
+    dev = json.loads((Path(bench.ROOT) / "profiles" / "devcount_traffic.json").read_text()) if (Path(bench.ROOT) / "profiles" / "devcount_traffic.json").exists() else {}
+    if dev.get("kernel_source_sha16") == sha:
+        assert "cartpole_2p20" in dev["configs"] and set(bench.EXTRA_CONFIGS) <= set(dev["configs"])
+        for name, rec in dev["configs"].items():
+            for path in ("per_step_visible", "chain"):
+                assert rec[path]["bytes_per_launch"] > 0 and rec[path]["fetch_bytes"] >= 0 and rec[path]["write_bytes"] > 0, (name, path)
+        checked += 1
+    pmc = json.loads((Path(bench.ROOT) / "profiles" / "pmc_traffic.json").read_text())
+    if pmc.get("kernel_source_sha16") == sha:
+        for env in ("cartpole", "mountain_car", "pendulum"):
+            for path in ("per_step_visible", "chain"):
+                assert pmc[env][path]["bytes_per_launch"] > 0 and pmc[env][path]["raw"]["FETCH_SIZE"]["launches"] > 0, (env, path)
+        checked += 1
+    if not checked:
+        pytest.skip("the committed traffic files belong to other kernel sources (bench.py drops them as stale)")
