@@ -54,6 +54,9 @@ ENVS = {
     "mountain_car": (1, 1 << 20, 9, 13, "MountainCar-v0 @ 2^20 envs per GPU, f32, auto-reset, random policy"),
     "pendulum": (2, 1 << 22, 12, 25, "Pendulum-v1 (spec-derived) @ 2^22 envs per GPU, f32, auto-reset, 200-step time limit, random policy"),
 }
+# Bytes per env-step the kernels MOVE by construction when nothing is served by a cache: MountainCar's constant reward store is elided (22 - 4),
+# Pendulum's theta_dot observation column IS the state column and its flags are rewritten only when they change (37 - 4 - ~0.7)
+MOVED_BYTES = {"cartpole": 38.0, "mountain_car": 18.0, "pendulum": 32.3}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
 L2_PEAK_GBPS = 34500.0  # aggregate of the eight 4 MiB L2s, same guide ("L2 (per XCD)": ~34.5 TB/s): what bounds a cache-resident chain
 # The two call shapes of the per-step API (docstring above): name -> (GYMRS_AQL for the calls, what it is)
@@ -131,7 +134,7 @@ def load_free_running_traffic(config_name: str, path: str, sha: str):
     return rec, (None if rec else f"profiles/devcount_traffic.json has no entry for {config_name} / {path}")
 
 
-def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, kernel, sha):
+def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, kernel, sha, moved_bytes_per_step=None):
     """The roofline object of one call shape.  per_step_visible: the contract's HBM roofline (algorithmic bytes / launch time / 8 TB/s; SURVEY
     H1b: at 2^20 lanes the arrays pass through the Infinity Cache, so this is a fraction of the HBM ROOFLINE, not a claim about DRAM
     traffic -- `traffic` says what the fabric saw).  chain: the state lives in the L2s between launches, so the bound that applies is
@@ -139,7 +142,9 @@ def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, k
     achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
     # a chain is cache-resident while the fabric sees (far) less than the algorithmic bytes; where the figure is not on file: while one
     # step's arrays fit the L2s and the Infinity Cache comfortably.  Beyond that a chain streams from HBM like any other launch.
-    resident = (traffic_rec["bytes_per_launch"] < 0.9 * n * bytes_per_step) if traffic_rec else (n * bytes_per_step <= (128 << 20))
+    # ("less" is judged against what the kernel moves by construction: MountainCar and Pendulum count bytes they never store)
+    moved = moved_bytes_per_step or bytes_per_step
+    resident = (traffic_rec["bytes_per_launch"] < 0.9 * n * moved) if traffic_rec else (n * bytes_per_step <= (128 << 20))
     in_l2 = path == "chain" and resident
     peak = L2_PEAK_GBPS if in_l2 else HBM_PEAK_GBPS
     roof = {"bound": "l2" if in_l2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
@@ -158,7 +163,7 @@ def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, k
         roof["achieved_moved"] = traffic_rec["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
         roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
         if not in_l2:
-            roof["hbm_bound"] = roof["traffic_over_algorithmic"] >= 0.9
+            roof["hbm_bound"] = not resident
             if not roof["hbm_bound"]:
                 roof["frac_note"] = ("the fabric sees %.2f x the algorithmic bytes: part of what a step reads is still in the L2s / the Infinity Cache from the step "
                                      "before, so `frac` is a fraction of the HBM ROOFLINE (the contract's algorithmic bytes / time / 8 TB/s, SURVEY H1b), not HBM "
@@ -587,7 +592,7 @@ def run_rank(args, info, backend, make_collective=None):
                     "lead_in_repetition_us_per_step": t["lead_in_us"], "submission": submission_of(path, t)}
             if per_step:
                 trec, tnote = load_free_running_traffic(config_name, path, sha) if config_name else (None, "no committed traffic figure for this size / tuning")
-                prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha)
+                prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha, MOVED_BYTES[args.env])
                 prec["roofline"]["how"] = ("HIP events on the engine's stream around ONE gymrs_step_many(P*K) call / (P*K), median of the repetitions: the back-to-back "
                                            "launches with their gaps (for a chain also its hand-over from and back to the stream); rank 0's lanes")
             path_out[path] = prec
@@ -684,14 +689,14 @@ def run_rank(args, info, backend, make_collective=None):
                 rd16, wr16 = n * bytes_read // 16 * 16, n * bytes_written // 16 * 16
                 for path, prec in path_out.items():
                     base = 2 if path == "chain" else 0
-                    cands = [u for u in (backend.copy_probe(rd16, wr16, 500, base | h) for h in (1, 0, 4)) if u]
+                    cands = [u for u in (backend.copy_probe(rd16, wr16, 500, base | h) for h in (1, 0, 4, 9, 8, 12)) if u]
                     if not cands:
                         continue
                     us_same = min(cands)
                     roof = prec["roofline"]
                     roof["same_footprint_copy_us"] = us_same
                     roof["same_footprint_copy"] = (f"{bytes_read} B read + {bytes_written} B written per lane, {n} lanes per launch, back-to-back launches submitted like "
-                                                   f"this call shape ({'launches of a chain' if path == 'chain' else 'HIP launches'}), in place like a step, the best of three hint choices: "
+                                                   f"this call shape ({'launches of a chain' if path == 'chain' else 'HIP launches'}), in place like a step, the best of three hint choices x two shapes (4 / 1 items per work-item): "
                                                    "the floor of a step launch of this size")
                     roof["frac_of_same_footprint_copy"] = us_same / roof["launch_us"]
                     if us_big and path != "chain":
@@ -784,7 +789,7 @@ def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=Fals
             ex = json.loads(eng.env_json(0))["gymrs"]
         launch_us = statistics.median(us)
         trec, tnote = load_free_running_traffic(config_name, path, sha)
-        roof = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, ex.get("last_launch"), sha)
+        roof = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, ex.get("last_launch"), sha, MOVED_BYTES[env_name])
         roof["frac_counted"], roof["achieved_counted"] = roof["frac"], roof["achieved"]
         if trec and roof["bound"] == "hbm":  # first-class = what is moved
             roof["achieved"], roof["frac"] = roof["achieved_moved"], roof["frac_moved"]
@@ -795,7 +800,7 @@ def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=Fals
         if not no_probe:
             rd16, wr16 = n * bytes_read // 16 * 16, n * bytes_written // 16 * 16
             base = 2 if path == "chain" else 0
-            cands = [u for u in (backend.copy_probe(rd16, wr16, max(20, int(2e3 / launch_us)), base | h) for h in (1, 0, 4)) if u]
+            cands = [u for u in (backend.copy_probe(rd16, wr16, max(20, int(2e3 / launch_us)), base | h) for h in (1, 0, 4, 9, 8, 12)) if u]
             if cands:
                 roof["same_footprint_copy_us"] = min(cands)
                 roof["frac_of_same_footprint_copy"] = min(cands) / launch_us

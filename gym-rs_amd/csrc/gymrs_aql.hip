@@ -285,7 +285,7 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe), "hsa_executable_create_alt");
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
-    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck", "gymrs_aql_copy_probe_pl", "gymrs_aql_copy_probe_nt", "gymrs_aql_copy_probe_st"};
+    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck", "gymrs_aql_copy_probe_pl", "gymrs_aql_copy_probe_nt", "gymrs_aql_copy_probe_st", "gymrs_aql_copy_probe_pl1", "gymrs_aql_copy_probe_nt1", "gymrs_aql_copy_probe_st1"};
     for (const char* env_threads : {"cartpole_f%d_t512", "cartpole_f%d_t256", "mountain_car_f%d_t256", "pendulum_f%d_t256"}) // (gymrs_step_aql.hip)
         for (int flags : {0, 1, 3, 4, 5, 7})
             for (const char* hint : {"_nt", "_o", "_so", "_pl"}) {

@@ -397,13 +397,13 @@ __global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* src,
     copy_probe_body<NTL, NTS, ITEMS>(src, n_read16, dst, n_write16);
 }
 
-// hint: 0 none, 1 loads and stores non-temporal, 2 stores only
-hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, hipStream_t stream)
+// hint: 0 none, 1 loads and stores non-temporal, 2 stores only; items: 16-byte items per work-item (kCopyProbeItems, or 1)
+hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, int items_per_thread, hipStream_t stream)
 {
     const uint64_t items = n_read16 > n_write16 ? n_read16 : n_write16;
     if (items == 0) return hipSuccess;
-    const bool big = (n_read16 + n_write16) * 16 >= kCopyProbeBigBytes;
-    const uint64_t per_block = (uint64_t)kBlock * (big ? 1 : kCopyProbeItems);
+    const bool one = items_per_thread == 1;
+    const uint64_t per_block = (uint64_t)kBlock * (one ? 1 : kCopyProbeItems);
     const uint64_t grid = (items + per_block - 1) / per_block;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const uint32_t* s = static_cast<const uint32_t*>(src);
@@ -411,7 +411,7 @@ hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint
     const dim3 g((uint32_t)grid), b(kBlock);
 #define GYMRS_COPY_LAUNCH(NTL_, NTS_)                                                                                                  \
     do {                                                                                                                               \
-        if (big) hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, 1>), g, b, 0, stream, s, n_read16, d, n_write16);                   \
+        if (one) hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, 1>), g, b, 0, stream, s, n_read16, d, n_write16);                   \
         else hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, kCopyProbeItems>), g, b, 0, stream, s, n_read16, d, n_write16);         \
     } while (0)
     if (hint == 1) GYMRS_COPY_LAUNCH(true, true);

@@ -2237,8 +2237,8 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
                               double* us_per_launch)
 {
     if (!us_per_launch || launches == 0) return fail(GYMRS_EINVAL, "gymrs_copy_probe: NULL output or zero launches");
-    if (mode < 0 || mode > 7 || (mode & 5) == 5)
-        return fail(GYMRS_EINVAL, "gymrs_copy_probe: mode = hint (0 none, 1 loads and stores non-temporal, 4 stores only) | 2 for launches through a chain");
+    if (mode < 0 || mode > 15 || (mode & 5) == 5)
+        return fail(GYMRS_EINVAL, "gymrs_copy_probe: mode = hint (0 none, 1 loads and stores non-temporal, 4 stores only) | 2 for launches through a chain | 8 for one item per work-item");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(GYMRS_EHIP, "gymrs_copy_probe: no HIP device available; this library has no CPU fallback");
     if (device < 0 || device >= n_dev) return fail(GYMRS_EINVAL, "gymrs_copy_probe: device index out of range");
@@ -2247,6 +2247,7 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
     const bool chained = (mode & 2) != 0;
     const uint64_t n_read = read_bytes / 16, n_write = write_bytes / 16;
     const bool big = (n_read + n_write) * 16 >= kCopyProbeBigBytes;
+    const int items_per_thread = (big || (mode & 8)) ? 1 : kCopyProbeItems;
     if (chained && big) return fail(GYMRS_EINVAL, "gymrs_copy_probe: the chained form is for a step's footprint (< 1.5 GiB per launch)");
     void *src = nullptr, *dst = nullptr;
     hipStream_t stream = nullptr;
@@ -2270,17 +2271,17 @@ gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_by
         // the same copy as launches of a CHAIN on a dispatcher queue of its own (acquire only, the release at the end of the chain): what a
         // chain's step has to be compared with -- the HIP-launched copy carries a release fence per launch, a chain's step does not
         chain = aql_create(device, &why);
-        if (!chain || !aql_kernel(chain, non_temporal == 1 ? "gymrs_aql_copy_probe_nt" : (non_temporal == 2 ? "gymrs_aql_copy_probe_st" : "gymrs_aql_copy_probe_pl"), &k)) chain_failed = true;
+        if (!chain || !aql_kernel(chain, (std::string(non_temporal == 1 ? "gymrs_aql_copy_probe_nt" : (non_temporal == 2 ? "gymrs_aql_copy_probe_st" : "gymrs_aql_copy_probe_pl")) + (items_per_thread == 1 ? "1" : "")).c_str(), &k)) chain_failed = true;
         if (!chain_failed) (void)aql_calibrate(chain, stream, true);
     }
     auto run = [&](uint32_t count) -> hipError_t {
         if (!chained) {
             hipError_t e2 = hipSuccess;
-            for (uint32_t i = 0; i < count && e2 == hipSuccess; ++i) e2 = launch_copy_probe(src, n_read, dst, n_write, non_temporal, stream);
+            for (uint32_t i = 0; i < count && e2 == hipSuccess; ++i) e2 = launch_copy_probe(src, n_read, dst, n_write, non_temporal, items_per_thread, stream);
             return e2;
         }
         const uint64_t items = n_read > n_write ? n_read : n_write;
-        const uint64_t per_block = (uint64_t)kBlock * kCopyProbeItems;
+        const uint64_t per_block = (uint64_t)kBlock * items_per_thread;
         const uint32_t grid = (uint32_t)((items + per_block - 1) / per_block);
         CopyProbeKernArgs ka{static_cast<const uint32_t*>(src), n_read, static_cast<uint32_t*>(dst), n_write};
         if (k.kernarg_bytes != sizeof(ka)) {

@@ -7,7 +7,11 @@
 
 namespace gymrs {
 
+#ifdef GYMRS_EXP_BLOCK // (developer builds, HIP launches only: the workgroup size of every kernel that uses kBlock; profiles/r04_wave_variants.log)
+constexpr int kBlock = GYMRS_EXP_BLOCK;
+#else
 constexpr int kBlock = 256; // work-items per workgroup of the small kernels (reset, fill, statistics) and of the rollout kernel
+#endif
 constexpr uint32_t kFlagNonTemporal = 0x100u; // internal launch flag (not an engine flag): non-temporal loads/stores
 // Hints per class of access, for the launches of a chain (gymrs_aql.h): only the stores nobody reads again (reward, done,
 // truncated, Pendulum's cos / sin), and additionally the state LOADS (the state stores stay plain: the next launch reads them
@@ -191,8 +195,8 @@ hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
 // device words of scratch; the result goes to host_out2 (device-visible host memory): [0] = the age, then [1] = seq.
 hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
                           hipStream_t stream);
-// gymrs_copy_probe: reads n_read16 and writes n_write16 16-byte items; kCopyProbeItems items per work-item, one from
-// kCopyProbeBigBytes per launch on (gymrs_aux.hip says why)
+// gymrs_copy_probe: reads n_read16 and writes n_write16 16-byte items; kCopyProbeItems items per work-item or one (the caller's choice;
+// always one from kCopyProbeBigBytes per launch on: gymrs_aux.hip says why)
 constexpr int kCopyProbeItems = 4;
 constexpr uint64_t kCopyProbeBigBytes = 1536ull << 20;
 struct CopyProbeKernArgs { // the kernel-argument segment of the copy probe's kernels as the engine's own dispatcher fills it
@@ -201,6 +205,6 @@ struct CopyProbeKernArgs { // the kernel-argument segment of the copy probe's ke
     uint32_t* dst;
     uint64_t n_write16;
 };
-hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int non_temporal, hipStream_t stream);
+hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, int items_per_thread, hipStream_t stream);
 
 } // namespace gymrs

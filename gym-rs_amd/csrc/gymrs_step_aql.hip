@@ -43,6 +43,10 @@ GYMRS_AQL_STEP_FLAGSETS(pendulum, PendulumT, 256)
     extern "C" __global__ __launch_bounds__(kBlock) void NAME_(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)       \
     {                                                                                                                                         \
         copy_probe_body<NTL_, NTS_, kCopyProbeItems>(src, n_read16, dst, n_write16);                                                          \
+    }                                                                                                                                         \
+    extern "C" __global__ __launch_bounds__(kBlock) void NAME_##1(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)    \
+    {                                                                                                                                         \
+        copy_probe_body<NTL_, NTS_, 1>(src, n_read16, dst, n_write16); /* one item per work-item */                                           \
     }
 GYMRS_AQL_COPY(gymrs_aql_copy_probe_pl, false, false) // hints: none
 GYMRS_AQL_COPY(gymrs_aql_copy_probe_nt, true, true)   // loads and stores

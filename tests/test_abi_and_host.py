@@ -269,8 +269,8 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
             for flags in (0, 1, 3, 4, 5, 7):
                 for hint in ("nt", "o", "so", "pl"):
                     names.append(f"gymrs_aql_{env}_f{flags}_t{threads}_{hint}".encode())
-    names += [b"gymrs_aql_copy_probe_pl", b"gymrs_aql_copy_probe_nt", b"gymrs_aql_copy_probe_st"]  # gymrs_copy_probe through a chain
-    assert len(names) == 102
+    names += [b"gymrs_aql_copy_probe_" + h + i for h in (b"pl", b"nt", b"st") for i in (b"", b"1")]  # gymrs_copy_probe through a chain
+    assert len(names) == 105
     for name in names:
         assert blob.count(name + b".kd") >= 1, name
     # (which variant a launch used is reported by the engine itself: gymrs_env_json(...)["gymrs"]["last_launch"], bench.py's roofline.kernel)
@@ -293,6 +293,9 @@ def test_bench_rooflines_are_fractions_of_the_bound_that_applies():
     nofile = bench.roofline_of("chain", n, b, 4.9, None, "why", "k", "sha")
     assert nofile["bound"] == "l2" and nofile["traffic"] is None and nofile["traffic_note"] == "why"
     assert bench.roofline_of("chain", 1 << 24, b, 99.0, None, "why", "k", "sha")["bound"] == "hbm"
+    # Pendulum counts 37 B per env-step and moves ~32.3 by construction: 0.875 x the algorithmic bytes on the fabric is NOT cache residency
+    pend = bench.roofline_of("chain", 1 << 22, 37, 23.0, {"bytes_per_launch": 135.6e6}, None, "k", "sha", bench.MOVED_BYTES["pendulum"])
+    assert pend["bound"] == "hbm" and pend["hbm_bound"] is True
 
 
 def test_committed_traffic_files_cover_both_call_shapes():

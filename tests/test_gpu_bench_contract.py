@@ -125,7 +125,7 @@ def test_the_drivers_own_command_reports_the_kernel_limited_rate(driver_line):
         assert 0.5 < p["roofline"]["frac_of_same_footprint_copy"] <= 1.05, p["roofline"]
     for name, c in cfgs.items():
         for path, p in c["paths"].items():
-            assert 0.5 < p["roofline"]["frac_of_same_footprint_copy"] <= 1.08, (name, path, p["roofline"])
+            assert 0.5 < p["roofline"]["frac_of_same_footprint_copy"] <= 1.10, (name, path, p["roofline"])
 
 
 def test_default_form_prints_the_contract_line():

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 4, call 11: the XCD check against a LOCAL table entry (plain store by the first launch, tagged with the chain number), one wave per workgroup: cost per env; then the suite
+# round 4, call 10: the XCD check with its table load hidden behind an uncounted asm statement, one wave per workgroup (a WRONG state in the first chain of the suite: abandoned): cost per env; then the suite
 set -u
-OUT=gpurun_out/r04_c11; mkdir -p $OUT
+OUT=gpurun_out/r04_c10; mkdir -p $OUT
 export TMPDIR=/tmp
 for env in 1 0 2; do
   GYMRS_AQL=1 timeout 600 python tools/step_timer.py --env $env --lib _ab/libr03.so --lib _ab/libx0.so --lib gym-rs_amd/libgymrs_amd.so --steps 5000 --reps 9 > $OUT/ab_env${env}_chain.log 2>&1

@@ -72,10 +72,14 @@ struct Streams {
     uint64_t n4; // work-item tiles
 };
 
-// TILES tiles per work-item in flight (all their loads issued before the first store); persistent grid-stride over groups of tiles
-template <int THREADS, int TILES, bool NTL, bool NTS>
+// TILES tiles per work-item in flight (all their loads issued before the first store); persistent grid-stride over groups of tiles.
+// ALU (round 4, the mid-size question): ALU rounds of 16 independent FMAs per work-item between a tile's loads and its stores -- the real step
+// issues ~380 VALU instructions per wave there (ALU = 24) and holds its bytes for ~3 us; LDS_KB pads the workgroup's LDS like ResetLds does.
+template <int THREADS, int TILES, bool NTL, bool NTS, int ALU = 0, int LDS_KB = 0>
 __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
 {
+    __shared__ uint32_t pad_lds[LDS_KB > 0 ? LDS_KB * 256 : 1];
+    if (LDS_KB > 0 && a.n4 == 0xffffffffffull) pad_lds[threadIdx.x] = 1; // (never true: keeps the allocation)
     const uint64_t chunk = (uint64_t)THREADS * TILES;
     for (uint64_t c = blockIdx.x; c * chunk < a.n4; c += gridDim.x) {
         const uint64_t first = c * chunk + threadIdx.x;
@@ -95,6 +99,27 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
             const uint64_t i = first + (uint64_t)t * THREADS;
             if (i < a.n4) {
                 v[t][0].x += 1u;
+                if constexpr (ALU > 0) {
+                    float f[16];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f[4 * j + 0] = __builtin_bit_cast(float, v[t][j].x);
+                        f[4 * j + 1] = __builtin_bit_cast(float, v[t][j].y);
+                        f[4 * j + 2] = __builtin_bit_cast(float, v[t][j].z);
+                        f[4 * j + 3] = __builtin_bit_cast(float, v[t][j].w);
+                    }
+                    for (int r = 0; r < ALU; ++r) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) f[q] = __builtin_fmaf(f[q], 1.0000001f, 1e-30f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[t][j].y = __builtin_bit_cast(uint32_t, f[4 * j + 1]);
+                        v[t][j].z = __builtin_bit_cast(uint32_t, f[4 * j + 2]);
+                        v[t][j].w = __builtin_bit_cast(uint32_t, f[4 * j + 3]);
+                        if (j) v[t][j].x = __builtin_bit_cast(uint32_t, f[4 * j]);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) st16<NTS>(a.s_out[j] + i, v[t][j]);
                 st16<NTS>(a.reward + i, v[t][3]);
@@ -245,6 +270,28 @@ int main(int argc, char** argv)
                     STREAM_VARIANT(256, 2, true, true, 256 * 4)
                     STREAM_VARIANT(256, 2, true, true, 256 * 8)
                     STREAM_VARIANT(256, 4, true, true, 256 * 4)
+                    // the mid-size question: the same streams with the step's arithmetic between loads and stores (plain loads, hinted stores)
+#define ALU_VARIANT(THREADS_, TILES_, ALU_, LDS_)                                                                                          \
+    {                                                                                                                                     \
+        const uint64_t full = (n4 + (uint64_t)THREADS_ * TILES_ - 1) / ((uint64_t)THREADS_ * TILES_);                                    \
+        char l[96];                                                                                                                       \
+        std::snprintf(l, sizeof(l), "%d thr x %d tiles, plain loads + nt stores, %d FMA rounds, %d KB LDS", THREADS_, TILES_, ALU_, LDS_); \
+        report(l, time_launches(st, 20, [&] {                                                                                            \
+                   hipLaunchKernelGGL((stream_kernel<THREADS_, TILES_, false, true, ALU_, LDS_>), dim3((uint32_t)full), dim3(THREADS_), 0, st, a); \
+               }));                                                                                                                       \
+    }
+                    if (inplace) {
+                        ALU_VARIANT(512, 1, 0, 0)
+                        ALU_VARIANT(512, 1, 12, 0)
+                        ALU_VARIANT(512, 1, 24, 0)
+                        ALU_VARIANT(512, 1, 48, 0)
+                        ALU_VARIANT(512, 1, 96, 0)
+                        ALU_VARIANT(512, 1, 24, 36)
+                        ALU_VARIANT(256, 1, 24, 0)
+                        ALU_VARIANT(256, 1, 24, 18)
+                        ALU_VARIANT(512, 2, 24, 0)
+                        ALU_VARIANT(256, 2, 48, 0)
+                    }
                 } else {
                     STREAM_VARIANT(256, 2, true, true, 256 * 4)
                 }
