@@ -54,6 +54,25 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _native_backtrace_on_fatal_signals(tmp_path_factory):
+    """GYMRS_TEST_SEGV_TRACE=1: print the native backtrace of the crashing thread on SIGSEGV & co (tests/cpp/segv_trace.c), then let python's
+    faulthandler have its say.  Installed once the session is up, i.e. over faulthandler's own handler."""
+    import os
+
+    if os.environ.get("GYMRS_TEST_SEGV_TRACE") != "1":
+        yield
+        return
+    import ctypes
+    import subprocess
+
+    out = tmp_path_factory.mktemp("segv") / "libsegv_trace.so"
+    subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", str(Path(__file__).resolve().parent / "cpp" / "segv_trace.c"), "-o", str(out)], check=True)
+    lib = ctypes.CDLL(str(out))
+    assert lib.gymrs_test_install_segv_trace() == 0
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

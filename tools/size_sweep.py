@@ -62,7 +62,8 @@ def main():
             stt = lib.gymrs_copy_probe(0, n * rd // 16 * 16, n * wr // 16 * 16, max(20, steps // 4), hint | chained, C.byref(us))
             out.append(us.value if stt == 0 else float("nan"))
         gbps = n * (rd + wr) / (best * 1e-6) / 1e9
-        print(f"2^{lg:2d} lanes: step {best:9.2f} us  {gbps:7.1f} GB/s algorithmic ({gbps / 8000:.3f} of 8 TB/s)   in-place copy, {'chain' if chained else 'HIP launches'}: "
+        frac = "" if chained else f" ({gbps / 8000:.3f} of 8 TB/s)"  # (a chain's state is read out of the L2s at the small sizes: no HBM fraction)
+        print(f"2^{lg:2d} lanes: step {best:9.2f} us  {gbps:7.1f} GB/s algorithmic{frac}   in-place copy, {'chain' if chained else 'HIP launches'}: "
               f"plain {out[0]:8.2f}  hinted {out[1]:8.2f}  stores hinted {out[2]:8.2f} us   step/copy {best / min(out):.3f}", flush=True)
 
 
