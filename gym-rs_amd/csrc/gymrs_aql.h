@@ -43,6 +43,7 @@ class AqlChain;
 // One chain object per engine (its own HSA queue).  nullptr + *why when the path is not available: no large-BAR access to
 // device memory, no stream memory operations, a failed self-check, GYMRS_AQL=0, ...
 AqlChain* aql_create(int hip_device, std::string* why);
+// parks the object (queue, rings, flags) for the next aql_create on the device: hardware queues are created once, not per engine
 void aql_destroy(AqlChain* c);
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out);
 
@@ -68,5 +69,8 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream);
 // [8] device words of this chain object for StepArgs::xcc_table: the first step launch of a chain records where its workgroups run,
 // the later launches of the chain compare (gymrs_kernels.h says why the table is per chain and not per queue or per device).
 uint32_t* aql_xcc_table(const AqlChain* c);
+// the number of the chain that is open (aql_begin counts; 24 bits): the tag of its table entries.  It belongs to the chain OBJECT, which
+// outlives engines (aql_destroy parks it for the next engine of the device), so no two chains that ever wrote one table share a tag.
+uint32_t aql_chain_number(const AqlChain* c);
 
 } // namespace gymrs

@@ -109,7 +109,11 @@ struct DeviceCtx {
     // it last looked.  A queue that goes away moves nobody (destroying an engine used to re-calibrate every other one).
     std::atomic<uint32_t> epoch{0};
     float* calib_buf = nullptr; // scratch of aql_calibrate's probe chains (allocated once, at the self-check: no hipMalloc later)
-    std::atomic<int> live{0}; // chain objects (= HSA queues) alive on this device
+    std::atomic<int> live{0}; // chain objects (= HSA queues) alive on this device, in use or parked
+    // Chain objects whose engine is gone, parked for the next engine (guarded by g_mu): an HSA queue is created once and reused, not
+    // destroyed and re-created with every engine -- engines come and go by the hundred in a test suite or a hyper-parameter sweep,
+    // hardware queues should not (round 4: the dispatcher is set up at engine creation, which made every engine a queue).
+    std::vector<AqlChain*> parked;
 };
 
 // Every chain object is a hardware queue of its own next to the HIP runtime's; a process that creates engines by the dozen must
@@ -482,6 +486,8 @@ bool init_device(DeviceCtx* c, int device, std::string* why)
 
 } // namespace
 
+static void aql_discard(AqlChain* c);
+
 AqlChain* aql_create(int hip_device, std::string* why)
 {
     std::string local;
@@ -500,6 +506,23 @@ AqlChain* aql_create(int hip_device, std::string* why)
         if (!c->ok) {
             *why = c->why;
             return nullptr;
+        }
+    }
+    {   // a parked chain object first: its queue, ring and flags are idle (its engine synchronised its stream before letting go of it)
+        std::lock_guard<std::mutex> lock(g_mu);
+        while (!c->parked.empty()) {
+            AqlChain* ch = c->parked.back();
+            c->parked.pop_back();
+            if (ch->queue_status.load() != 0) { // (a queue that reported an error is not handed on)
+                aql_discard(ch);
+                continue;
+            }
+            ch->in_chain = false;
+            ch->staged.clear();
+            ch->calibrated = false; // the next engine's stream is another one
+            ch->sync_mode = ch->forced_sync;
+            if (ch->host_err) ch->host_err[0] = 0;
+            return ch;
         }
     }
     if (c->live.fetch_add(1, std::memory_order_relaxed) >= kMaxChainsPerDevice) {
@@ -588,7 +611,8 @@ AqlChain* aql_create(int hip_device, std::string* why)
     return ch;
 }
 
-void aql_destroy(AqlChain* c)
+// really gives the queue back (a chain object whose queue reported an error, or whose set-up failed half-way)
+static void aql_discard(AqlChain* c)
 {
     if (!c) return;
     if (c->ctx) c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
@@ -600,6 +624,20 @@ void aql_destroy(AqlChain* c)
     if (c->out_flag) (void)hipFree(c->out_flag);
     if (c->host_err) (void)hipHostFree(c->host_err);
     delete c;
+}
+
+// The engine is done with its chain object (its stream is idle: every chain ended with a wait on it).  A complete, healthy object is
+// parked for the next engine of the device; anything else is discarded.
+void aql_destroy(AqlChain* c)
+{
+    if (!c) return;
+    const bool complete = c->ctx && c->q && c->kernarg && c->xcc_table && c->in_flag && c->out_flag && c->host_err && c->done.handle;
+    if (!complete || c->in_chain || c->queue_status.load() != 0) {
+        aql_discard(c);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_mu);
+    c->ctx->parked.push_back(c);
 }
 
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out)
@@ -733,6 +771,7 @@ const char* aql_calibrate(AqlChain* c, hipStream_t stream, bool own_stream)
 }
 
 uint32_t* aql_xcc_table(const AqlChain* c) { return c->xcc_table; }
+uint32_t aql_chain_number(const AqlChain* c) { return c->seq & 0xffffffu; }
 
 uint32_t aql_take_error(AqlChain* c)
 {

@@ -1411,7 +1411,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         // every wavefront of a chain launch checks where it runs; the chain's first launch records the table (StepArgs::xcc_table)
         a.xcc_table = aql_xcc_table(e->aql);
         a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
-        a.xcc_seq = (uint32_t)((e->aql_chains + 1) & 0xffffffu); // (aql_chains counts the CLOSED chains: constant while this one is open)
+        a.xcc_seq = aql_chain_number(e->aql);
         e->chain_first = false;
         if (no_xcc_check) a.xcc_check = 0u;
         bool ok = false;

@@ -86,7 +86,12 @@ def main():
 
         for _ in range(args.ops):
             op = rng.choices(["many_long", "many_short", "many_graph", "step", "step_host", "rollout", "stats_clear", "reset", "set_state", "set_params",
-                              "clone", "sync"], weights=[8, 3, 2, 3, 1, 2, 1, 1, 1, 2, 1, 1])[0]
+                              "clone", "sync", "hint"], weights=[8, 3, 2, 3, 1, 2, 1, 1, 1, 2, 1, 1, 2])[0]
+            if op == "hint":  # (round 4) another memory hint = another instantiation of the same kernel, for HIP launches and for chains: never another result
+                h = rng.randrange(4)
+                log.append(f"set_tuning memory_hint {h}")
+                eng.set_tuning(4, h)
+                continue
             if op in ("many_long", "many_short", "many_graph"):
                 graph = op == "many_graph"
                 if graph and kind == 2 and (flags & 4):
