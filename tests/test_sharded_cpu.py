@@ -403,3 +403,49 @@ print(json.dumps(out))
     assert out["uuid"] is None and out["missing"] is None
     assert out["fallback"]["node"] is None and out["fallback"]["mine"] is not None  # index-based block, as before
     assert out["off"] == [None, None, True]
+
+
+def test_allreduce_stats_raises_instead_of_ending_the_process(monkeypatch):
+    """ShardedRun.allreduce_stats used to call os._exit(3) on ANY failure of the native call.  Now an ordinary failure of the C ABI call is
+    re-raised as it is, and a collective that never completes raises TimeoutError and marks the run abandoned (bench.py then leaves through its own
+    hard exit after printing; a library user sees an exception)."""
+    import time
+
+    gymrs = importlib.import_module("gym-rs_amd")
+    sharded = gymrs.sharded
+
+    class Engine:
+        def __init__(self, mode):
+            self.mode = mode
+
+        def allreduce_stats(self):
+            if self.mode == "fails":
+                raise gymrs.GymrsError(3, "ncclAllReduce: unhandled system error")
+            time.sleep(5.0)
+            return [0.0] * 4
+
+        def stats(self):
+            return [1.0, 2.0, 3.0, 4.0]
+
+    class Coll:
+        active = False
+
+        def sum(self, x):
+            return x
+
+    info = sharded.RankInfo(rank=0, local_rank=0, world=1, launched=False)
+    run = sharded.ShardedRun(info, 16, Coll(), lambda off, n: Engine("fails"))
+    run.allreduce_path = "gymrs_allreduce_stats (RCCL via the C ABI)"
+    with pytest.raises(gymrs.GymrsError, match="ncclAllReduce"):
+        run.allreduce_stats()
+    assert run.abandoned is False
+    monkeypatch.setenv("GYMRS_COMM_TIMEOUT", "0.2")
+    run = sharded.ShardedRun(info, 16, Coll(), lambda off, n: Engine("hangs"))
+    run.allreduce_path = "gymrs_allreduce_stats (RCCL via the C ABI)"
+    t0 = time.perf_counter()
+    with pytest.raises(TimeoutError, match="did not complete"):
+        run.allreduce_stats()
+    assert run.abandoned is True and time.perf_counter() - t0 < 3.0
+    # without the native path the statistics go through the collective the run was given
+    run = sharded.ShardedRun(info, 16, Coll(), lambda off, n: Engine("fails"))
+    assert list(run.allreduce_stats()) == [1.0, 2.0, 3.0, 4.0]
