@@ -316,10 +316,12 @@ bool load_code(DeviceCtx* c, std::string* why)
 #endif
 }
 
-bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why)
+// `status` = where the queue's error callback reports (it must outlive the queue AND any late callback of the runtime's event thread):
+// the chain object's own word for the long-lived objects, a static word for the self-check's short-lived queue.
+bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why, std::atomic<int>* status = nullptr)
 {
     static const uint32_t queue_packets = [] { const char* v = std::getenv("GYMRS_AQL_QUEUE"); return v ? (uint32_t)std::strtoul(v, nullptr, 0) : kQueuePackets; }();
-    HSA_OK(hsa_queue_create(c->gpu, queue_packets, HSA_QUEUE_TYPE_SINGLE, queue_error, &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
+    HSA_OK(hsa_queue_create(c->gpu, queue_packets, HSA_QUEUE_TYPE_SINGLE, queue_error, status ? status : &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
     void* ka = nullptr;
     HSA_OK(hsa_amd_memory_pool_allocate(c->gpu_pool, (size_t)kKernargSlots * kAqlKernargSlot, 0, &ka), "kernel-argument ring");
     ch->kernarg = static_cast<char*>(ka);
@@ -349,7 +351,8 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
     hsa_signal_t done{};
     constexpr uint32_t kLaunches = 96, kGroups = 1022; // 1022 workgroups: not a multiple of 8, the last one partial
     do {
-        if (!make_queue(c, &ch, why)) break;
+        static std::atomic<int> self_check_queue_status{0}; // (`ch` lives on this stack frame; the callback's word must not)
+        if (!make_queue(c, &ch, why, &self_check_queue_status)) break;
         const uint32_t n4 = (kGroups - 1u) * 256u + 77u;
         if (hipMalloc(&x, (size_t)n4 * 16) != hipSuccess || hipMalloc(&flag, 64) != hipSuccess || hipMalloc(&xcc, 2 * kGroups * sizeof(uint32_t)) != hipSuccess) {
             *why = "self-check: hipMalloc failed";
@@ -428,9 +431,9 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = buf;
             break;
         }
-        // The production kernels re-check this in every launch against a table of 8 entries: the deal must repeat with period 8
-        // (round-robin over the XCDs; a partition with fewer XCDs repeats with a divisor of 8, which is fine too).
-        uint32_t aperiodic = 0, map = 0;
+        // The production kernels check every launch of a chain against a table of 8 entries (one per residue class of the workgroup index):
+        // the deal must repeat with period 8 (round-robin over the XCDs; a partition with fewer XCDs repeats with a divisor of 8: fine too).
+        uint32_t aperiodic = 0;
         for (uint32_t g = 0; g < kGroups; ++g) aperiodic += where[g] != where[g & 7u];
         if (aperiodic) {
             char buf[160];
@@ -439,7 +442,7 @@ bool self_check(DeviceCtx* c, int device, std::string* why)
             *why = buf;
             break;
         }
-        (void)map; // (the table itself is read per queue: probe_xcc_map)
+        // (the table itself is recorded by the first launch of every chain: StepArgs::xcc_table)
         ok = true;
     } while (false);
     if (done.handle) hsa_signal_destroy(done);
@@ -623,7 +626,8 @@ static void aql_discard(AqlChain* c)
     if (c->in_flag) (void)hipFree(c->in_flag);
     if (c->out_flag) (void)hipFree(c->out_flag);
     if (c->host_err) (void)hipHostFree(c->host_err);
-    delete c;
+    // (an object that owned a queue is not freed: the queue's error callback holds a pointer into it, and this is a rare error path)
+    if (!c->q) delete c;
 }
 
 // The engine is done with its chain object (its stream is idle: every chain ended with a wait on it).  A complete, healthy object is

@@ -148,8 +148,8 @@ struct gymrs_engine {
     uint64_t age_ref_tick = 0;          // tick the ages of the refresh in flight are measured from
     uint64_t age_next_refresh = 0;      // no new refresh before this tick (doubling back-off while the limit stays reachable)
     uint32_t age_backoff = 8;
-    // The engine's own AQL dispatcher for chains of per-step launches (gymrs_aql.h): created at the first gymrs_step_many that
-    // can use it; aql_why says why not when it stays NULL.
+    // The engine's own AQL dispatcher for chains of per-step launches (gymrs_aql.h): set up by gymrs_engine_create (or, for an engine created
+    // under GYMRS_AQL=0, by the first gymrs_step_many that can use it); aql_why says why not when it stays NULL.
     AqlChain* aql = nullptr;
     bool aql_tried = false;
     bool chain_open = false; // gymrs_step_many is inside aql_begin .. aql_end: see stream_op_barrier
@@ -1517,12 +1517,12 @@ gymrs_status gymrs_sync(gymrs_engine* e)
                                     "hand-over point within ~10 s (is it blocked on work that was never submitted?)");
         }
     }
-    if (const uint32_t where = e->err_seen[1]) { // a wavefront of a chain launch found itself on another XCD than the self-check saw
+    if (const uint32_t where = e->err_seen[1]) { // a wavefront of a chain launch found itself on another XCD than the chain's first launch recorded
         e->err_seen[1] = 0;
         aql_destroy(e->aql); // (the stream is idle: every chain ended with a wait on it)
         e->aql = nullptr;
         char buf[400];
-        std::snprintf(buf, sizeof(buf), "a gymrs_step_many chain ran workgroup %u on another XCD than the dispatcher's self-check saw for that index: the launches of a "
+        std::snprintf(buf, sizeof(buf), "a gymrs_step_many chain ran workgroup %u on another XCD than the chain's first launch recorded for its index: the launches of a "
                                         "chain carry no release fence, so the arrays may hold stale values since the last gymrs_sync; this engine now steps through HIP launches",
                       where - 1u);
         e->aql_why = "a chain launch ran on an unexpected XCD; HIP launches from then on";
