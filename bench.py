@@ -686,6 +686,8 @@ def run_rank(args, info, backend, make_collective=None):
                 big = 1 << 30
                 both = [u for u in (backend.copy_probe(big, big, 20, 1), backend.copy_probe(big, big, 20, 0)) if u]
                 us_big = min(both) if both else None
+                zeros = [u for u in (backend.copy_probe(big, big, 20, 16 | 1), backend.copy_probe(big, big, 20, 16)) if u]
+                us_big_zeros = min(zeros) if zeros else None
                 rd16, wr16 = n * bytes_read // 16 * 16, n * bytes_written // 16 * 16
                 for path, prec in path_out.items():
                     base = 2 if path == "chain" else 0
@@ -695,14 +697,19 @@ def run_rank(args, info, backend, make_collective=None):
                     us_same = min(cands)
                     roof = prec["roofline"]
                     roof["same_footprint_copy_us"] = us_same
+                    zeros = [u for u in (backend.copy_probe(rd16, wr16, 500, 16 | base | h) for h in (1, 0, 4, 9, 8, 12)) if u]
+                    if zeros:
+                        roof["same_footprint_copy_of_zeros_us"] = min(zeros)  # (what every figure before evidence set r04e was: lines of zeros move faster)
                     roof["same_footprint_copy"] = (f"{bytes_read} B read + {bytes_written} B written per lane, {n} lanes per launch, back-to-back launches submitted like "
-                                                   f"this call shape ({'launches of a chain' if path == 'chain' else 'HIP launches'}), in place like a step, the best of three hint choices x two shapes (4 / 1 items per work-item): "
+                                                   f"this call shape ({'launches of a chain' if path == 'chain' else 'HIP launches'}), in place like a step, a source of hashed 32-bit words (NOT zeros: profiles/r04_copy_content.log), the best of three hint choices x two shapes (4 / 1 items per work-item): "
                                                    "the floor of a step launch of this size")
                     roof["frac_of_same_footprint_copy"] = us_same / roof["launch_us"]
                     if us_big and path != "chain":
                         roof["peak_measured"] = {"hbm_copy_GBps": 2 * big / (us_big * 1e-6) / 1e9,
-                                                 "hbm_copy": "1 GiB read + 1 GiB written per launch (beyond the 256 MiB Infinity Cache), dwordx4 copy kernel, one "
+                                                 "hbm_copy": "1 GiB of hashed 32-bit words read + 1 GiB written per launch (beyond the 256 MiB Infinity Cache), dwordx4 copy kernel, one "
                                                              "item per work-item, the better of streaming-hinted and plain accesses"}
+                        if us_big_zeros:
+                            roof["peak_measured"]["hbm_copy_of_zeros_GBps"] = 2 * big / (us_big_zeros * 1e-6) / 1e9
                         roof["frac_of_measured_hbm_copy"] = roof["achieved"] / roof["peak_measured"]["hbm_copy_GBps"]
         else:
             # The fused kernel touches HBM once per launch of R steps: it is bound by VALU issue, not by HBM.  Its roofline is

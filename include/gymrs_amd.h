@@ -293,7 +293,8 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* json, void*
  * box (it includes the fixed cost of a dependent launch); from 1.5 GiB per launch on (1 GiB + 1 GiB: two buffers, one item per work-item,
  * the shape that streams fastest) it is the HBM bandwidth a kernel can actually get.  mode = hint (0 none, 1 non-temporal loads and stores, 4 non-temporal stores only -- what leaves the
  * Infinity Cache to the bytes that are read again) | 8: one item per work-item instead of four | 2: the launches go through a chain of the library's own dispatcher (acquire-only packets, one release at the end: what gymrs_step_many's chains must be compared with; a
- * step's footprint only; GYMRS_EHIP where the dispatcher is not available). */
+ * step's footprint only; GYMRS_EHIP where the dispatcher is not available) | 16: the source holds zeros.  Without 16 it holds hashed 32-bit words: on this part
+ * lines of zeros move 3-14 % faster than any other content (profiles/r04_copy_content.log), and a step's arrays are not zeros. */
 gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int mode,
                               double* us_per_launch);
 

@@ -5,6 +5,11 @@ from pathlib import Path
 
 import pytest
 
+sys.path.insert(0, str(Path(__file__).resolve().parent))
+import spawn_server  # noqa: E402
+
+spawn_server.start()  # before torch (hence the HIP runtime) is imported: the tests' child processes are forked by a process that never loads it
+
 ROOT = Path(__file__).resolve().parent.parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
@@ -73,10 +78,9 @@ def _native_backtrace_on_fatal_signals(tmp_path_factory):
         yield
         return
     import ctypes
-    import subprocess
 
     out = tmp_path_factory.mktemp("segv") / "libsegv_trace.so"
-    subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", str(Path(__file__).resolve().parent / "cpp" / "segv_trace.c"), "-o", str(out)], check=True)
+    spawn_server.run(["gcc", "-O1", "-g", "-shared", "-fPIC", str(Path(__file__).resolve().parent / "cpp" / "segv_trace.c"), "-o", str(out)], check=True)
     lib = ctypes.CDLL(str(out))
     assert lib.gymrs_test_install_segv_trace() == 0
     yield

@@ -4,7 +4,7 @@ LOUDLY without a GPU (no CPU fallback); lane sharding + the statistics all-reduc
 import ctypes as C
 import os
 import re
-import subprocess
+import spawn_server
 import sys
 from pathlib import Path
 
@@ -136,7 +136,7 @@ def test_two_rank_sharding_and_allreduce_gloo(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29541", str(script), str(ROOT)]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    res = spawn_server.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "SHARD_OK" in res.stdout
 
@@ -146,14 +146,14 @@ def test_cpp_trait_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
     torch types in the signatures); without a GPU it must stop with the library's own error, not fall back."""
     exe = tmp_path / "test_env_mirror"
     lib_dir = ROOT / "gym-rs_amd"
-    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "test_env_mirror.cpp"),
+    spawn_server.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'include'}", str(ROOT / "tests" / "cpp" / "test_env_mirror.cpp"),
                     "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
                    check=True, capture_output=True, text=True)
     import torch
 
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: the run is covered by tests/test_gpu_envs.py::test_cpp_trait_mirror")
-    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    res = spawn_server.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert res.returncode != 0 and "no CPU fallback" in (res.stdout + res.stderr)
 
 
@@ -180,9 +180,9 @@ int main(void) {
 ''')
     exe = tmp_path / "caller"
     lib_dir = ROOT / "gym-rs_amd"
-    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+    spawn_server.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
                     f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"], check=True, capture_output=True, text=True)
-    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    res = spawn_server.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert res.returncode == 0, res.stdout + res.stderr
     assert res.stdout.split() == ["2", "3.5", "0.20943951023931953", "1", "4", "4.0"]
 
@@ -245,10 +245,10 @@ def test_json_numbers_are_laid_out_like_serde_json(tmp_path):
     src.write_text('#include "gymrs_json.h"\n#include <cstdio>\n#include <cstdlib>\nint main(int, char** a){ FILE* f = fopen(a[1], "rb"); double v; '
                    'while (fread(&v, 8, 1, f) == 1) std::printf("%s\\n", gymrs::json::number(v).c_str()); return 0; }\n')
     exe = tmp_path / "num"
-    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'gym-rs_amd' / 'csrc'}", str(src), "-o", str(exe)], check=True)
+    spawn_server.run(["g++", "-std=c++17", "-O1", f"-I{ROOT / 'gym-rs_amd' / 'csrc'}", str(src), "-o", str(exe)], check=True)
     data = tmp_path / "vals.bin"
     data.write_bytes(b"".join(struct.pack("<d", v) for v in vals))
-    out = subprocess.run([str(exe), str(data)], capture_output=True, text=True, check=True).stdout.split()
+    out = spawn_server.run([str(exe), str(data)], capture_output=True, text=True, check=True).stdout.split()
     assert len(out) == len(vals)
     for v, text in zip(vals, out):
         assert float(text) == v, (v, text)           # round-trips

@@ -111,16 +111,16 @@ def test_mutable_physics_fields(gymrs):
 
 def test_cpp_trait_mirror(tmp_path):
     """include/gymrs_env.hpp (the C++ host side above the C ABI) on the GPU: tests/cpp/test_env_mirror.cpp."""
-    import subprocess
+    import spawn_server
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
     exe = tmp_path / "test_env_mirror"
     lib_dir = root / "gym-rs_amd"
-    subprocess.run(["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_env_mirror.cpp"),
+    spawn_server.run(["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_env_mirror.cpp"),
                     "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
                    check=True, capture_output=True, text=True)
-    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    res = spawn_server.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "CPP_MIRROR_OK" in res.stdout, res.stdout + res.stderr
 
 
@@ -174,12 +174,12 @@ def test_closed_loop_example_runs_and_balances(tmp_path):
     """examples/closed_loop_policy.py: zero-copy observation columns in torch, a linear policy on the engine's
     stream.  The controller keeps the pole up far longer than the ~22 steps of a random policy."""
     import re
-    import subprocess
+    import spawn_server
     import sys
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    out = subprocess.run([sys.executable, str(root / "examples" / "closed_loop_policy.py"), "--n-envs", "8192", "--steps", "600"],
+    out = spawn_server.run([sys.executable, str(root / "examples" / "closed_loop_policy.py"), "--n-envs", "8192", "--steps", "600"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-1500:]
     m = re.search(r"finished episodes: (\d+), mean return ([0-9.]+)", out.stdout)

@@ -187,3 +187,6 @@ def test_copy_probe_reports_a_plausible_floor(gymrs):
     gbps = 2 * (1 << 29) / (us.value * 1e-6) / 1e9
     assert 3000.0 < gbps < 8000.0  # HBM3E: 8 TB/s peak, ~6.3 TB/s for a float4 copy
     assert lib.gymrs_copy_probe(99, 16, 16, 1, 0, C.byref(us)) == 1
+    # mode | 16: a source of zeros (what the probe copied before round 4's last evidence set); no other bit above 8 exists
+    assert lib.gymrs_copy_probe(0, 17 * n, 21 * n, 50, 16 | 1, C.byref(us)) == 0 and 2.0 < us.value < 12.0
+    assert lib.gymrs_copy_probe(0, 17 * n, 21 * n, 50, 32, C.byref(us)) == 1

@@ -5,7 +5,7 @@ standing in for the GPU shard (it supplies ONLY the per-shard stepping and stati
 import importlib
 import json
 import os
-import subprocess
+import spawn_server
 import sys
 from pathlib import Path
 
@@ -192,7 +192,7 @@ def run_workers(tmp_path, world, comm_mode="none", timeout=900, extra_env=None):
     script.write_text(WORKER)
     cmd = gymrs.sharded.spawn_command(str(script), [str(ROOT), str(tmp_path), str(world), comm_mode], world)
     env = dict(os.environ, OMP_NUM_THREADS="1", **(extra_env or {}))
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    res = spawn_server.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("RESULT ")]
     assert len(line) == 1, res.stdout[-2000:]
@@ -302,7 +302,7 @@ def test_plain_multi_gpu_form_spawns_ranks_and_fails_loudly_without_gpus():
 
     if torch.cuda.is_available():
         pytest.skip("a GPU is present: covered by tests/test_gpu_bench_contract.py")
-    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"],
+    res = spawn_server.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"],
                          cwd=ROOT, capture_output=True, text=True, timeout=300)
     text = res.stdout + res.stderr
     assert res.returncode != 0
@@ -328,7 +328,7 @@ mine, before = sh.pin_rank_to_cpus(0, env={"GYMRS_NO_CPU_PIN": "1"})
 out["off"] = [mine, sorted(os.sched_getaffinity(0)) == allowed]
 print(json.dumps(out))
 '''
-    res = subprocess.run([sys.executable, "-c", code, str(ROOT)], capture_output=True, text=True, timeout=120)
+    res = spawn_server.run([sys.executable, "-c", code, str(ROOT)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     allowed = out["allowed"]
@@ -385,7 +385,7 @@ mine, before, node = sh.pin_rank_near_gpu(3, n_local_ranks=8, sysfs=root, env={"
 out["off"] = [mine, node, sorted(os.sched_getaffinity(0)) == allowed]
 print(json.dumps(out))
 '''
-    res = subprocess.run([sys.executable, "-c", code, str(ROOT), str(tmp_path / "sys")], capture_output=True, text=True, timeout=120)
+    res = spawn_server.run([sys.executable, "-c", code, str(ROOT), str(tmp_path / "sys")], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr[-3000:]
     out = json.loads(res.stdout.strip().splitlines()[-1])
     allowed = out["allowed"]

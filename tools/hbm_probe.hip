@@ -4,11 +4,12 @@
 // and done written as packed dwords, reward written -- 17 B read + 21 B written per lane, nine streams.
 // Knobs: grid shape (one tile per workgroup vs persistent grid-stride), tiles in flight per work-item, workgroup size,
 // non-temporal hints on loads / stores separately, the skew between the array bases.
-//   hipcc --offload-arch=gfx950 -O3 tools/hbm_probe.hip -o tools/hbm_probe && tools/hbm_probe [lanes_log2=24]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++20 tools/hbm_probe.hip -o tools/hbm_probe && tools/hbm_probe [lanes_log2=24]
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <vector>
 
@@ -62,6 +63,29 @@ __global__ __launch_bounds__(THREADS) void copy_kernel(const u4* __restrict__ sr
     }
 }
 
+// (d) what the bytes ARE: fill a buffer with zeros / one byte value / hashed 32-bit words / small floats (a CartPole state: |x| < 0.05..2.4, mixed signs)
+__global__ void fill_kernel(uint32_t* p, uint64_t n32, int kind)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t h = (uint32_t)i * 2654435761u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        uint32_t v = 0;
+        if (kind == 1) v = 0x01010101u;
+        else if (kind == 2) v = 0xffffffffu;
+        else if (kind == 3) v = h;
+        else if (kind == 4) v = __builtin_bit_cast(uint32_t, ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f);   // uniform in [-0.05, 0.05)
+        else if (kind == 5) v = __builtin_bit_cast(uint32_t, ((float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f) * 4.8f);   // uniform in [-2.4, 2.4)
+        else if (kind == 6) v = 0x3f800000u;                                                                             // 1.0f everywhere
+        else if (kind == 7) v = (h & 0x01010101u);                                                                       // random 0/1 bytes (actions, flags)
+        p[i] = v;
+    }
+}
+static const char* fill_name(int kind)
+{
+    static const char* n[8] = {"zeros", "0x01 bytes", "0xff bytes", "hashed 32-bit words", "floats in [-0.05, 0.05)", "floats in [-2.4, 2.4)", "1.0f everywhere", "random 0/1 bytes"};
+    return n[kind];
+}
+
 // ---- (b) the step's nine streams.  One "tile" of a work-item = 4 consecutive lanes: 4 x dwordx4 + 1 dword in, 5 x dwordx4 + 1 dword out.
 struct Streams {
     const u4* s_in[4];
@@ -70,6 +94,9 @@ struct Streams {
     u4* reward;
     uint32_t* done;
     uint64_t n4; // work-item tiles
+    uint32_t stag_units, stag_wgs; // (c): workgroup b < stag_wgs starts (b >> 8) * stag_units * 0.21 us late (the k-th workgroup a CU receives: k units)
+    uint32_t delay_units;          // (c): after a tile's loads have landed the wave sleeps delay_units * 0.21 us (no VALU work) before it stores
+    uint32_t mode;                 // (c): 0 loads and stores, 1 loads only (the stores sit behind a test that never holds), 2 stores only
 };
 
 // TILES tiles per work-item in flight (all their loads issued before the first store); persistent grid-stride over groups of tiles.
@@ -80,6 +107,8 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
 {
     __shared__ uint32_t pad_lds[LDS_KB > 0 ? LDS_KB * 256 : 1];
     if (LDS_KB > 0 && a.n4 == 0xffffffffffull) pad_lds[threadIdx.x] = 1; // (never true: keeps the allocation)
+    if (a.stag_units && blockIdx.x < a.stag_wgs)
+        for (uint32_t i = 0; i < (blockIdx.x >> 8) * a.stag_units; ++i) __builtin_amdgcn_s_sleep(8);
     const uint64_t chunk = (uint64_t)THREADS * TILES;
     for (uint64_t c = blockIdx.x; c * chunk < a.n4; c += gridDim.x) {
         const uint64_t first = c * chunk + threadIdx.x;
@@ -89,10 +118,20 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
         for (int t = 0; t < TILES; ++t) {
             const uint64_t i = first + (uint64_t)t * THREADS;
             if (i < a.n4) {
+                if (a.mode == 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[t][j] = ld16<NTL>(a.s_in[j] + i);
-                act[t] = ld4<NTL>(a.act + i);
+                    for (int j = 0; j < 4; ++j) v[t][j] = u4{(uint32_t)i, 1u, 2u, 3u};
+                    act[t] = (uint32_t)i;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[t][j] = ld16<NTL>(a.s_in[j] + i);
+                    act[t] = ld4<NTL>(a.act + i);
+                }
             }
+        }
+        if (a.delay_units) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = 0; i < a.delay_units; ++i) __builtin_amdgcn_s_sleep(8);
         }
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -120,6 +159,7 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
                         if (j) v[t][j].x = __builtin_bit_cast(uint32_t, f[4 * j]);
                     }
                 }
+                if (a.mode == 1 && (v[t][0].x ^ v[t][1].y ^ v[t][2].z ^ v[t][3].w ^ act[t]) != 0x9e3779b9u) continue; // loads only (the pool is zero-filled)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) st16<NTS>(a.s_out[j] + i, v[t][j]);
                 st16<NTS>(a.reward + i, v[t][3]);
@@ -155,10 +195,74 @@ static double time_launches(hipStream_t st, int launches, const auto& launch)
 int main(int argc, char** argv)
 {
     const int lanes_log2 = argc > 1 ? std::atoi(argv[1]) : 24;
+    const bool phase_only = argc > 2 && !std::strcmp(argv[2], "phase"); // only part (c)
+    const bool data_only = argc > 2 && !std::strcmp(argv[2], "data");   // only part (d)
     hipStream_t st;
     HIP_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (data_only) {
+        // ---------------- (d) does the CONTENT of the bytes matter? ----------------
+        std::printf("# (d) the same copies over different CONTENT (every fill is followed by the same launches; the order A B A ... excludes time under load)\n");
+        std::printf("%-96s %10s %10s\n", "variant", "us", "GB/s");
+        {
+            const uint64_t bytes = 1ull << 30, n16 = bytes / 16;
+            u4 *src, *dst;
+            HIP_OK(hipMalloc(&src, bytes + 4096));
+            HIP_OK(hipMalloc(&dst, bytes + 4096));
+            for (int kind : {0, 3, 0, 4, 1, 5, 6, 7, 2, 3, 0}) {
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, (uint32_t*)src, bytes / 4, kind);
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, (uint32_t*)dst, bytes / 4, 0);
+                HIP_OK(hipStreamSynchronize(st));
+                const uint32_t grid = (uint32_t)((n16 + 255) / 256);
+                const double us = time_launches(st, 10, [&] { hipLaunchKernelGGL((copy_kernel<256, 1, true, true>), dim3(grid), dim3(256), 0, st, src, dst, n16); });
+                char l[128];
+                std::snprintf(l, sizeof(l), "1 GiB -> 1 GiB, one item per work-item, hinted | %s", fill_name(kind));
+                std::printf("%-96s %10.2f %10.0f\n", l, us, 2.0 * bytes / (us * 1e-6) / 1e9);
+                std::fflush(stdout);
+            }
+            HIP_OK(hipFree(src));
+            HIP_OK(hipFree(dst));
+        }
+        {
+            const uint64_t n = 1ull << lanes_log2, n4 = n / 4;
+            const double alg = (double)n * 38.0;
+            const size_t arr = n * 4, skew = 4352;
+            char* pool;
+            const size_t pool_bytes = arr * 9 + n * 2 + skew * 16 + (1 << 20);
+            HIP_OK(hipMalloc(&pool, pool_bytes));
+            Streams a{};
+            size_t off = 0;
+            int k = 0;
+            auto carve = [&](size_t bytes) {
+                char* p = pool + off + (size_t)(++k) * skew;
+                off += (bytes + 4095) / 4096 * 4096;
+                return p;
+            };
+            for (int j = 0; j < 4; ++j) { a.s_in[j] = (const u4*)carve(arr); a.s_out[j] = (u4*)a.s_in[j]; }
+            a.reward = (u4*)carve(arr);
+            a.act = (const uint32_t*)carve(n);
+            a.done = (uint32_t*)carve(n);
+            a.n4 = n4;
+            const uint64_t full = (n4 + 511) / 512;
+            for (int kind : {0, 3, 0, 4, 5, 1, 6, 7, 2, 3, 0}) {
+                hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, (uint32_t*)pool, pool_bytes / 4, kind);
+                HIP_OK(hipStreamSynchronize(st));
+                for (int alu : {0, 24}) {
+                    const double us = alu == 0
+                        ? time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 0, 0>), dim3((uint32_t)full), dim3(512), 0, st, a); })
+                        : time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 24, 0>), dim3((uint32_t)full), dim3(512), 0, st, a); });
+                    char l[128];
+                    std::snprintf(l, sizeof(l), "the step's nine streams at 2^%d lanes, in place, %2d FMA rounds | %s%s", lanes_log2, alu, fill_name(kind),
+                                  alu ? " (then what the FMAs leave)" : "");
+                    std::printf("%-96s %10.2f %10.0f\n", l, us, alg / (us * 1e-6) / 1e9);
+                    std::fflush(stdout);
+                }
+            }
+            HIP_OK(hipFree(pool));
+        }
+        return 0;
+    }
     // ---------------- (a) 1 GiB -> 1 GiB ----------------
-    {
+    if (!phase_only) {
         const uint64_t bytes = 1ull << 30, n16 = bytes / 16;
         u4 *src, *dst;
         HIP_OK(hipMalloc(&src, bytes + 4096));
@@ -217,6 +321,7 @@ int main(int argc, char** argv)
         for (uint64_t skew : {0ull, 4352ull, 256ull * 37, 256ull * 1021, 4096ull * 3 + 256}) {
             for (int inplace = 1; inplace >= 0; --inplace) {
                 if (!inplace && skew != 4352) continue;
+                if (phase_only && !(inplace && skew == 4352)) continue;
                 // one pool, arrays carved with base k * skew apart from their power-of-two spacing (the engine: multiples of 4352 B)
                 const size_t arr = n * 4;
                 char* pool;
@@ -254,6 +359,67 @@ int main(int argc, char** argv)
                    hipLaunchKernelGGL((stream_kernel<THREADS_, TILES_, NTL_, NTS_>), dim3(grid), dim3(THREADS_), 0, st, a);              \
                }));                                                                                                                       \
     }
+                if (phase_only) {
+                    // ---------------- (c) is it the arithmetic, or WHEN the waves do what? ----------------
+                    // A launch of several generations of waves starts its first generation all at once: every resident wave loads, then computes, then
+                    // stores at the same time, and the next generation inherits the alignment (a slot frees when its workgroup ends).  (i) a pure delay
+                    // between loads and stores (no VALU work at all) against the same time spent in FMAs; (ii) the first generation staggered by slot.
+#define PHASE_VARIANT(THREADS_, ALU_, STAG_, DELAY_)                                                                                      \
+    {                                                                                                                                     \
+        const uint64_t full = (n4 + (uint64_t)THREADS_ - 1) / (uint64_t)THREADS_;                                                        \
+        Streams b = a;                                                                                                                    \
+        b.stag_units = (STAG_);                                                                                                           \
+        b.stag_wgs = 256u * (THREADS_ == 512 ? 4 : 8);                                                                                    \
+        b.delay_units = (DELAY_);                                                                                                         \
+        char l[96];                                                                                                                       \
+        std::snprintf(l, sizeof(l), "%d thr, %d FMA rounds, sleep %.2f us, stagger %.2f us per slot", THREADS_, ALU_, (DELAY_) * 0.213, (STAG_) * 0.213); \
+        report(l, time_launches(st, 20, [&] {                                                                                            \
+                   hipLaunchKernelGGL((stream_kernel<THREADS_, 1, false, true, ALU_, 0>), dim3((uint32_t)full), dim3(THREADS_), 0, st, b); \
+               }));                                                                                                                       \
+    }
+                    PHASE_VARIANT(512, 0, 0, 0)
+                    PHASE_VARIANT(512, 24, 0, 0)
+                    for (int d : {1, 2, 4, 8, 16}) PHASE_VARIANT(512, 0, 0, d)
+                    for (int g : {1, 2, 4, 8, 16}) PHASE_VARIANT(512, 24, g, 0)
+                    for (int g : {2, 8}) PHASE_VARIANT(512, 0, g, 0)
+                    for (int g : {2, 8}) PHASE_VARIANT(512, 0, g, 4)
+                    PHASE_VARIANT(256, 24, 0, 0)
+                    for (int g : {1, 2, 4, 8}) PHASE_VARIANT(256, 24, g, 0)
+                    // (iii) which half of the traffic minds: the loads alone and the stores alone, in lockstep, staggered, delayed
+                    for (uint32_t m : {1u, 2u}) {
+                        a.mode = m;
+                        std::printf("# mode %u: %s only (GB/s still counts 38 B per lane)\n", m, m == 1 ? "loads (17 B per lane)" : "stores (21 B per lane)");
+                        PHASE_VARIANT(512, 0, 0, 0)
+                        PHASE_VARIANT(512, 0, 2, 0)
+                        PHASE_VARIANT(512, 0, 8, 0)
+                        PHASE_VARIANT(512, 0, 0, 4)
+                        PHASE_VARIANT(512, 24, 0, 0)
+                    }
+                    a.mode = 0;
+                    // (iv) one generation per launch: the same streams as k launches of n / k lanes each (k HIP launches back to back: each pays its own
+                    // release + acquire, which a chain's launches would not)
+#define SPLIT_VARIANT(THREADS_, ALU_, K_)                                                                                                 \
+    {                                                                                                                                     \
+        const uint64_t part = n4 / (K_);                                                                                                  \
+        const uint64_t full = (part + (uint64_t)THREADS_ - 1) / (uint64_t)THREADS_;                                                      \
+        char l[96];                                                                                                                       \
+        std::snprintf(l, sizeof(l), "%d thr, %d FMA rounds, as %d launches of %llu lanes", THREADS_, ALU_, K_, (unsigned long long)(part * 4)); \
+        report(l, time_launches(st, 20, [&] {                                                                                            \
+                   for (int q = 0; q < (K_); ++q) {                                                                                       \
+                       Streams b = a;                                                                                                     \
+                       for (int j = 0; j < 4; ++j) { b.s_in[j] = a.s_in[j] + q * part; b.s_out[j] = a.s_out[j] + q * part; }              \
+                       b.reward = a.reward + q * part; b.act = a.act + q * part; b.done = a.done + q * part;                              \
+                       b.n4 = part;                                                                                                       \
+                       hipLaunchKernelGGL((stream_kernel<THREADS_, 1, false, true, ALU_, 0>), dim3((uint32_t)full), dim3(THREADS_), 0, st, b); \
+                   }                                                                                                                      \
+               }));                                                                                                                       \
+    }
+                    for (int k : {1, 2, 4, 8, 16}) SPLIT_VARIANT(512, 24, k)
+                    for (int k : {1, 2, 4, 8}) SPLIT_VARIANT(512, 0, k)
+                    for (int k : {2, 4, 8}) SPLIT_VARIANT(256, 24, k)
+                    HIP_OK(hipFree(pool));
+                    continue;
+                }
                 STREAM_VARIANT(512, 1, true, true, 0) // the step's launch shape today (CartPole: 512 work-items, every access hinted)
                 if (skew == 4352) {
                     STREAM_VARIANT(256, 1, true, true, 0)
