@@ -541,11 +541,19 @@ def run_rank(args, info, backend, make_collective=None):
                 backend.sync()
             # One call per repetition: P passes of K steps = one gymrs_step_many(P * K).  One more repetition up front, reported but not
             # counted: whatever preceded the clock (stats_clear's kernels, the other call shape) has swept the caches.
-            walls, kernels = timed_repetitions(backend, coll, stream, lambda: run_steps(args.steps * passes), 1, reps + 1)
+            enqueue = []  # seconds until the call that enqueues a repetition returned: the launching thread's share
+
+            def one_repetition():
+                t = time.perf_counter()
+                run_steps(args.steps * passes)
+                enqueue.append(time.perf_counter() - t)
+
+            walls, kernels = timed_repetitions(backend, coll, stream, one_repetition, 1, reps + 1)
             ex = extras()
             chained = ex.get("aql_launches", 0) - before
             timed[path] = {"walls": walls[1:], "kernels": kernels[1:], "lead_in_us": kernels[0] * 1e3 / (args.steps * passes),
                            "own_us": [ms * 1e3 / (args.steps * passes) for ms in getattr(backend, "own_event_ms", kernels)[-reps:]],
+                           "enqueue_us": [e * 1e6 / (args.steps * passes) for e in enqueue[-reps:]],
                            "chained_launches": chained, "last_launch": ex.get("last_launch"), "handover": ex.get("aql_handover"),
                            "dispatcher": ex.get("aql")}
 
@@ -590,6 +598,10 @@ def run_rank(args, info, backend, make_collective=None):
                                           "spread": (max(t["kernels"]) - min(t["kernels"])) / kernel_ms},
                     "wall_ms_per_repetition": [w * 1e3 for w in t["walls"]], "event_ms_per_repetition": t["kernels"],
                     "lead_in_repetition_us_per_step": t["lead_in_us"], "submission": submission_of(path, t)}
+            if t["enqueue_us"]:
+                # rank 0's launching thread: how long the call that enqueues a repetition took, per launch.  Well below event_us_per_step = the device sets
+                # the pace; close to it = the thread does (HIP launches cost it 3-4 us each, a chain's 0.9), and the figure is the host's, not the kernel's
+                prec["host_enqueue_us_per_step"] = {"min": min(t["enqueue_us"]), "median": statistics.median(t["enqueue_us"]), "max": max(t["enqueue_us"])}
             if per_step:
                 trec, tnote = load_free_running_traffic(config_name, path, sha) if config_name else (None, "no committed traffic figure for this size / tuning")
                 prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha, MOVED_BYTES[args.env])
