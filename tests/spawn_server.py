@@ -33,7 +33,10 @@ while True:
     except subprocess.CalledProcessError as e:
         res = ("called", e.cmd, e.returncode, e.output, e.stderr)
     except BaseException as e:
-        res = ("error", repr(e), None, None, None)
+        try:
+            res = ("raised", pickle.dumps(e), None, None, None)
+        except Exception:
+            res = ("error", repr(e), None, None, None)
     blob = pickle.dumps(res)
     out.write(struct.pack("<Q", len(blob)))
     out.write(blob)
@@ -85,4 +88,6 @@ def run(*args, **kw):
         raise subprocess.TimeoutExpired(a, b, output=out, stderr=err)
     if kind == "called":
         raise subprocess.CalledProcessError(b, a, output=out, stderr=err)
+    if kind == "raised":
+        raise pickle.loads(a)  # (FileNotFoundError and the like: what subprocess.run itself would have raised)
     raise RuntimeError("the spawn helper could not run the command: " + a)
