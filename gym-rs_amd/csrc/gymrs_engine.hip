@@ -86,6 +86,7 @@ static StepArgs step_args(const gymrs_engine* e, const void* actions)
     a.reset_log = e->reset_log;
     a.reset_log_row_words = e->log_row_words;
     a.fold_step = 0;
+    a.elide_reward = e->elide_reward ? 1u : 0u;
     a.err = e->err;
     a.err_seen = e->err_seen_dev;
     a.n = e->n;
@@ -660,6 +661,17 @@ gymrs_status gymrs_engine_create(gymrs_env_kind kind, uint64_t n_envs, uint64_t 
     // MountainCar it would only spare the dense ep_start read, and under a random policy every lane is truncated in the
     // same step every 200 steps: the two refreshes and two exact launches per cycle cost what the 198 others gain.
     e->limit_elidable = kind == GYMRS_CARTPOLE && (flags & kAllThree) == kAllThree;
+    // CartPole under auto-reset pays 1.0 on every step (cartpole.rs:455-459), like MountainCar its -1.0: from kElideRewardFromBytes per step on the
+    // kernel stops rewriting a wave's part of `reward` while it holds the constant (StepArgs::elide_reward; 8-13 % of the step at 2^22 .. 2^25 lanes,
+    // profiles/r04_cartpole_reward_elision.log).  Below that the store stays: it is a wash there, and BASELINE's 2^20-lane configuration moves every
+    // byte it is credited with.  (GYMRS_DEV_ELIDE_REWARD=0|1: developer knob, forces it off / on at any size -- the tests' way to reach both paths.)
+    {
+        constexpr uint64_t kElideRewardFromBytes = 128ull << 20;
+        bool on = kind == GYMRS_CARTPOLE && (flags & GYMRS_AUTO_RESET) && n_envs * 42ull >= kElideRewardFromBytes; // (42 = bytes_per_step's figure for CartPole)
+        if (const char* v = std::getenv("GYMRS_DEV_ELIDE_REWARD"))
+            if (kind == GYMRS_CARTPOLE && (flags & GYMRS_AUTO_RESET) && (v[0] == '0' || v[0] == '1')) on = v[0] == '1';
+        e->elide_reward = on;
+    }
     if ((flags & GYMRS_TRACK_STATS) && (flags & GYMRS_AUTO_RESET) && kind == GYMRS_CARTPOLE &&
         (!(flags & GYMRS_TIME_LIMIT) || e->limit_elidable)) { // launches that are TileRegs<CartPoleT, ..>::LOGGED will happen
         // reset log: kResetLogRows rows of one bit per lane (2^20 lanes: 128 KiB per row)

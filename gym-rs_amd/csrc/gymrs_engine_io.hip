@@ -517,6 +517,8 @@ json::Object engine_extras(const gymrs_engine* e, uint64_t lane, uint32_t max_ep
         g.str("last_launch", buf);
     }
     g.str("aql", e->aql ? "on" : (e->aql_tried ? e->aql_why.c_str() : "not tried"));
+    // 1: the per-step kernel does not rewrite a wave's part of `reward` while it holds the env's constant reward (MountainCar always, CartPole from 128 MiB per step on)
+    g.uint("reward_store_elided", ((e->flags & GYMRS_AUTO_RESET) && (e->kind == GYMRS_MOUNTAIN_CAR || e->elide_reward)) ? 1 : 0);
     if (e->limit_elidable) { // diagnostics of the time-limit elision: launches that ran without the limit, bound refreshes
         g.uint("time_limit_elided_launches", e->limit_elided_launches).uint("time_limit_refreshes", e->age_refreshes);
         g.uint("time_limit_waits", e->age_waits).uint("time_limit_wait_us", e->age_wait_ns / 1000);

@@ -83,6 +83,7 @@ struct gymrs_engine {
     uint32_t* ep_start = nullptr;
     uint32_t* wave_clean = nullptr; // per-wavefront: its part of `reward` holds the env's constant reward (see step_block)
     int clean_shape = 0;           // lanes per workgroup row the flags were written with (vec * threads); 0 = all clear
+    bool elide_reward = false;     // CartPole with GYMRS_AUTO_RESET from kElideRewardFromBytes per step on: the constant reward store is elided like MountainCar's
     double* wave_open = nullptr; // per-wavefront sum of the rewards of the open episodes (Pendulum + TRACK_STATS)
     int open_vec = 0;            // lanes per work-item of the launch that last updated wave_open (0 = none yet)
     int trunc_held = -1;         // Pendulum: the uniform value the `truncated` array holds (-1 = unknown: write it)

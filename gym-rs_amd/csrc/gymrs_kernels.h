@@ -36,7 +36,7 @@ struct StepArgs {
     uint8_t* truncated; // written only with GYMRS_TIME_LIMIT
     uint8_t* beyond;    // CartPole without auto-reset: steps_beyond_terminated.is_some()
     uint32_t* ep_start; // tick at which the lane's current episode started (low 32 bits)
-    uint32_t* wave_clean; // [n_waves] constant-reward envs under auto-reset: != 0 = the wave's part of `reward` holds the constant
+    uint32_t* wave_clean; // [n_waves] constant-reward envs under auto-reset that elide the reward store: != 0 = the wave's part of `reward` holds the constant
     double* wave_open;  // [n_waves] Pendulum with GYMRS_TRACK_STATS: per-wavefront sum of the rewards of the open episodes
     unsigned long long* block_stats; // [n_waves][2] per-wavefront slots: finished episodes, sum of returns (f64 bits; Pendulum only)
     // Reset log (constant-reward envs with GYMRS_TRACK_STATS and without GYMRS_TIME_LIMIT): instead of one scattered 4-byte
@@ -47,6 +47,7 @@ struct StepArgs {
     unsigned long long* reset_log; // [kResetLogRows][reset_log_row_words]; word (wave * VEC + k), bit = work-item of the wave
     uint32_t reset_log_row_words;
     uint32_t fold_step;            // this launch folds the ring (wave-uniform branch in step_block)
+    uint32_t elide_reward;         // constant-reward envs whose kernel does not elide the reward store unconditionally (CartPole): != 0 = this engine elides it (step_block)
     uint32_t* err;      // [0] number of invalid actions seen, [1] lowest offending lane (0xffffffff = none)
     uint32_t* err_seen; // mapped host words: [0] a wave that saw an invalid action sets it to 1: gymrs_sync looks there first and
                         // fetches err[] only then (no device-to-host copy per synchronisation); [1] a wave of a CHAIN launch that found

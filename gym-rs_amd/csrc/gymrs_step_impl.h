@@ -109,11 +109,14 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
     }
     // MountainCar pays -1.0 on every step (mountain_car.rs:423; SURVEY 8a row a6 "may be elided ... but counted in
     // algorithmic bytes"): once a wave's part of `reward` holds the constant it is not rewritten until a step pays
-    // something else there (an invalid action).  A per-wave flag remembers it.  (CartPole under auto-reset is
-    // constant too, but its kernel is VALU-bound: there the flag load costs more than the stores save.)
-    constexpr bool ELIDE = AUTO && Env::kConstReward && Env::kElideConstReward;
+    // something else there (an invalid action).  A per-wave flag remembers it.  CartPole under auto-reset pays a constant
+    // too (cartpole.rs:455-459): its engines elide from 128 MiB per step on (StepArgs::elide_reward, a wave-uniform kernel
+    // argument) -- 2^22 lanes 25.5 -> 23.5 us, 2^24 98 -> 89, 2^25 214 -> 185 (profiles/r04_cartpole_reward_elision.log) -- and
+    // not below: the headline configuration moves every byte it is credited with.
+    constexpr bool CAN_ELIDE = AUTO && Env::kConstReward;
+    const bool elide = CAN_ELIDE && (Env::kElideConstReward || a.elide_reward != 0u);
     uint32_t clean = 0;
-    if (ELIDE) clean = a.wave_clean[wave_slot];
+    if (elide) clean = a.wave_clean[wave_slot];
     // Chains only (StepArgs::xcc_table): is this workgroup index still on the XCD the chain's first launch found its residue class (mod 8) on?
     // One wavefront per workgroup asks.  The table entry was stored PLAINLY by a workgroup of that first launch, so while the deal is
     // stable it is read out of this XCD's own L2 like the state (a table written through by another XCD took ~1 us to arrive and cost
@@ -137,7 +140,7 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
     GYMRS_STAMP(1);
     StepOut<VEC> out;
     advance_tile<Env, VEC, FLAGS, FULL, false, THREADS>(a, c, base, d, lds, old_resets, old_ret, open, out, vblock);
-    store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, ELIDE && clean != 0 && out.reward_is_const);
+    store_tile<Env, VEC, FLAGS, FULL>(a, base, d, out, elide && clean != 0 && out.reward_is_const);
     if (fold) {
         const uint32_t lane = threadIdx.x & 63u;
         // finished episodes of the wave in the ring's 8 steps: popcounts of the older words (one per lane) and of this step's masks
@@ -163,7 +166,7 @@ __device__ __forceinline__ void step_block_loaded(StepArgs a, const typename Env
             if (lane == 0) a.block_stats[wave_slot * 2] = old_resets + finished;
         }
     }
-    if (ELIDE && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
+    if (elide && (clean != 0) != out.reward_is_const && (threadIdx.x & 63u) == 0) a.wave_clean[wave_slot] = out.reward_is_const ? 1u : 0u;
     if (STATS && !Env::kConstReward && (threadIdx.x & 63u) == 0) a.wave_open[wave_slot] = open;
 #if GYMRS_EXP_XCC_PARTS & 4
     if (xcc_asks) { // (see above) the first launch of a chain records, every later one compares

@@ -148,7 +148,7 @@ struct CartPoleT {
     static constexpr int kSampled = 4; // state words reset() draws (cartpole.rs:317-324)
     static constexpr bool kConstReward = true;    // under auto-reset every step pays 1.0 (cartpole.rs:455-459)
     static constexpr float kReward = 1.0f;
-    static constexpr bool kElideConstReward = false; // measured: +1 % here (VALU-bound; the flag load costs more than 4 B per lane of stores)
+    static constexpr bool kElideConstReward = false; // not unconditionally: per engine, StepArgs::elide_reward (from 128 MiB per step on; at 2^20 lanes the flag load and the 4 B per lane are a wash)
 #ifdef GYMRS_EXP_NO_RESET_LOG // (developer builds: ablation)
     static constexpr bool kUseResetLog = false;
 #else

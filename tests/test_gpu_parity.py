@@ -682,3 +682,95 @@ def test_mountain_car_reward_array_stays_right_around_invalid_actions(gymrs, twi
     assert (eng.get_step_result()[0] == -1.0).all() and (other.get_step_result()[0] == -1.0).all()
     eng.close()
     other.close()
+
+
+@pytest.fixture
+def elide_reward_forced(monkeypatch):
+    """Engines created inside see GYMRS_DEV_ELIDE_REWARD (read at creation): CartPole's reward elision is a matter of size (from 128 MiB
+    per step on, 2^22 lanes); the knob puts both code paths within reach of a 9001-lane test."""
+    def force(value):
+        monkeypatch.setenv("GYMRS_DEV_ELIDE_REWARD", value)
+    return force
+
+
+@pytest.mark.parametrize("flag_set", ["A", "AS", "AST"])
+def test_cartpole_reward_elision_changes_nothing_but_the_stores(gymrs, twin, elide_reward_forced, flag_set):
+    """CartPole under auto-reset pays 1.0 on every step; big engines stop rewriting it (StepArgs::elide_reward).  Forced on at a small size:
+    HIP launches and chains against the twin -- state, rewards, flags, statistics -- with a 45-step time limit in the third flag set."""
+    import json
+
+    n, nbuf = 9001, 4
+    flags = gymrs.AUTO_RESET | (gymrs.TRACK_STATS if "S" in flag_set else 0) | (gymrs.TIME_LIMIT if "T" in flag_set else 0)
+    p = gymrs.engine.default_params(0)
+    p.max_episode_steps = 45
+    elide_reward_forced("1")
+    eng = gymrs.BatchedEngine(0, n, flags=flags, params=p)
+    assert json.loads(eng.env_json(0))["gymrs"]["reward_store_elided"] == 1
+    elide_reward_forced("0")
+    plain = gymrs.BatchedEngine(0, n, flags=flags, params=p)
+    assert json.loads(plain.env_json(0))["gymrs"]["reward_store_elided"] == 0
+    tw = TwinEngine(twin, 0, n, p, flags=flags)
+    for e in (eng, plain):
+        e.reset(seed=12)
+    tw.reset(12)
+    bufs = torch.empty((nbuf, n), dtype=torch.uint8, device="cuda:0")
+    for b in range(nbuf):
+        eng.fill_actions(bufs[b].data_ptr(), seed=5, t=b)
+
+    def same():
+        for e in (eng, plain):
+            e.sync()
+            assert np.array_equal(e.get_state().view(np.uint32), tw.get_state().view(np.uint32))
+            r, d, tr = e.get_step_result()
+            tr_, td, tt = tw.get_result()
+            assert np.array_equal(r.view(np.uint32), tr_.view(np.uint32)) and np.array_equal(d, td) and np.array_equal(tr, tt)
+            if "S" in flag_set:
+                assert np.array_equal(e.stats(), tw.stats())
+
+    for t in range(7):
+        for e in (eng, plain):
+            e.step(bufs[t % nbuf].data_ptr())
+        tw.step(tw.fill_actions(5, t % nbuf))
+        same()
+    for e in (eng, plain):
+        e.step_many(bufs.data_ptr(), n, nbuf, 61)  # a chain
+    for t in range(61):
+        tw.step(tw.fill_actions(5, t % nbuf))
+    same()
+    eng.close()
+    plain.close()
+
+
+def test_cartpole_reward_array_stays_right_around_invalid_actions_when_elided(gymrs, elide_reward_forced):
+    """The elided store's flag must fall when a step pays something else (an invalid action pays 0 and leaves the lane alone), and the next
+    step must put 1.0 back; a change of launch shape and a snapshot load start from "rewrite everything"."""
+    n = 5000
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    elide_reward_forced("1")
+    eng = gymrs.BatchedEngine(0, n, flags=flags)
+    eng.reset(seed=3)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    for t in range(3):
+        eng.fill_actions(buf.data_ptr(), seed=1, t=t)
+        eng.step(buf.data_ptr())
+        assert (eng.get_step_result()[0] == 1.0).all()
+    bad = torch.ones(n, dtype=torch.uint8, device="cuda:0")
+    bad[1234] = 7
+    eng.step(bad.data_ptr())
+    with pytest.raises(gymrs.InvalidActionError):
+        eng.sync()
+    r = eng.get_step_result()[0]
+    assert r[1234] == 0.0 and (np.delete(r, 1234) == 1.0).all()
+    eng.fill_actions(buf.data_ptr(), seed=1, t=4)
+    eng.step(buf.data_ptr())
+    eng.sync()
+    assert (eng.get_step_result()[0] == 1.0).all()
+    eng.set_tuning(8)
+    eng.step(buf.data_ptr())
+    other = gymrs.BatchedEngine(0, n, flags=flags)
+    other.reset(seed=8)
+    other.restore(eng.snapshot())
+    other.step(buf.data_ptr())
+    assert (eng.get_step_result()[0] == 1.0).all() and (other.get_step_result()[0] == 1.0).all()
+    eng.close()
+    other.close()
