@@ -109,7 +109,7 @@ def test_the_drivers_own_command_reports_the_kernel_limited_rate(driver_line):
     because a 40 us statistics read-out and its syncs sat inside a 0.28 ms wall-clock window."""
     d = driver_line
     # >= 9 repetitions taken in the settled state: they agree.  (VERDICT r2 "next" #2 asks for 2 %, and 1-2 % is what most runs show; the headline's HIP
-    # launches are host-sensitive, though, and one box in six of round 4's evidence runs dropped into a 6.8 us mode after the first repetition -- 7 % spread,
+    # launches are host-sensitive, though, and one box in ten of round 4's runs of the command dropped into a 6.8 us mode after the first repetition -- 7 % spread,
     # profiles/r04_bench_driver_form_slow_box.json.  The median is the figure; the bound only catches a run that fell apart.)
     assert d["timing"]["event_us_per_step"]["spread"] < 0.12, d["timing"]["event_us_per_step"]
     assert d["paths"]["chain"]["event_us_per_step"]["spread"] < 0.04, d["paths"]["chain"]["event_us_per_step"]  # (chains cost the host 0.9 us per launch: no such mode)
