@@ -225,7 +225,10 @@ gymrs_status gymrs_sync(gymrs_engine* e);
 /* ---- ActionReward{observation, reward, done, truncated} (core.rs:94-106), batched ------------ */
 /* Zero-copy SoA device views, valid until destroy.  CartPole obs = (x, x_dot, theta, theta_dot)
  * (cartpole.rs:336-349), MountainCar obs = (position, velocity) (mountain_car.rs:193-197); for
- * these the observation IS the state array.  Pendulum obs = (cos, sin, theta_dot). */
+ * these the observation IS the state array.  Pendulum obs = (cos, sin, theta_dot).
+ * The views are for READING: a step does not rewrite an output that already holds the right value (MountainCar's -1.0,
+ * CartPole's 1.0 on engines of >= 2^22 lanes, Pendulum's done / uniform truncated flag), so whoever overwrites the reward or
+ * flag arrays between two steps finds them repaired only by gymrs_reset or a snapshot load. */
 gymrs_status gymrs_obs_ptrs(gymrs_engine* e, float** out_ptrs /* capacity 4 */, int* obs_dim);
 gymrs_status gymrs_state_ptrs(gymrs_engine* e, float** out_ptrs /* capacity 4 */, int* state_dim);
 gymrs_status gymrs_reward_ptr(gymrs_engine* e, float** out);
