@@ -102,7 +102,8 @@ struct Streams {
 // TILES tiles per work-item in flight (all their loads issued before the first store); persistent grid-stride over groups of tiles.
 // ALU (round 4, the mid-size question): ALU rounds of 16 independent FMAs per work-item between a tile's loads and its stores -- the real step
 // issues ~380 VALU instructions per wave there (ALU = 24) and holds its bytes for ~3 us; LDS_KB pads the workgroup's LDS like ResetLds does.
-template <int THREADS, int TILES, bool NTL, bool NTS, int ALU = 0, int LDS_KB = 0>
+// AOS: the four state columns as ONE array of a float4 per LANE -- a work-item's 4 lanes are 64 contiguous bytes of s_in[0] (s_in[1..3] unused)
+template <int THREADS, int TILES, bool NTL, bool NTS, int ALU = 0, int LDS_KB = 0, bool AOS = false>
 __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
 {
     __shared__ uint32_t pad_lds[LDS_KB > 0 ? LDS_KB * 256 : 1];
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
                     act[t] = (uint32_t)i;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[t][j] = ld16<NTL>(a.s_in[j] + i);
+                    for (int j = 0; j < 4; ++j) v[t][j] = AOS ? ld16<NTL>(a.s_in[0] + 4 * i + j) : ld16<NTL>(a.s_in[j] + i);
                     act[t] = ld4<NTL>(a.act + i);
                 }
             }
@@ -161,7 +162,10 @@ __global__ __launch_bounds__(THREADS) void stream_kernel(Streams a)
                 }
                 if (a.mode == 1 && (v[t][0].x ^ v[t][1].y ^ v[t][2].z ^ v[t][3].w ^ act[t]) != 0x9e3779b9u) continue; // loads only (the pool is zero-filled)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) st16<NTS>(a.s_out[j] + i, v[t][j]);
+                for (int j = 0; j < 4; ++j) {
+                    if (AOS) st16<NTS>(a.s_out[0] + 4 * i + j, v[t][j]);
+                    else st16<NTS>(a.s_out[j] + i, v[t][j]);
+                }
                 st16<NTS>(a.reward + i, v[t][3]);
                 st4<NTS>(a.done + i, act[t] ^ 0x01010101u);
             }
@@ -257,6 +261,25 @@ int main(int argc, char** argv)
                     std::fflush(stdout);
                 }
             }
+            // (e) the four state columns as one float4-per-lane array (s_in[0] spans 4 arrays' worth: the pool is contiguous), hashed words, 0 / 24 FMA rounds
+            hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, (uint32_t*)pool, pool_bytes / 4, 3);
+            HIP_OK(hipStreamSynchronize(st));
+            for (int rep = 0; rep < 2; ++rep)
+                for (int aos = 0; aos < 2; ++aos)
+                    for (int alu : {0, 24}) {
+                        double us;
+                        if (aos)
+                            us = alu ? time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 24, 0, true>), dim3((uint32_t)full), dim3(512), 0, st, a); })
+                                     : time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 0, 0, true>), dim3((uint32_t)full), dim3(512), 0, st, a); });
+                        else
+                            us = alu ? time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 24, 0>), dim3((uint32_t)full), dim3(512), 0, st, a); })
+                                     : time_launches(st, 20, [&] { hipLaunchKernelGGL((stream_kernel<512, 1, false, true, 0, 0>), dim3((uint32_t)full), dim3(512), 0, st, a); });
+                        char l[128];
+                        std::snprintf(l, sizeof(l), "2^%d lanes, in place, %2d FMA rounds, hashed words | state as %s", lanes_log2, alu,
+                                      aos ? "ONE array of a float4 per lane (6 streams)" : "four columns (9 streams)");
+                        std::printf("%-96s %10.2f %10.0f\n", l, us, alg / (us * 1e-6) / 1e9);
+                        std::fflush(stdout);
+                    }
             HIP_OK(hipFree(pool));
         }
         return 0;
