@@ -69,7 +69,11 @@ PATHS = {
 HEADLINE_PATH = "per_step_visible"
 # VALU issue roofline of the fused rollout kernel: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
 VALU_PEAK_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 2
-MIN_REPETITION_SECONDS = 5e-3
+# A timed repetition = ONE gymrs_step_many call of P x K launches lasting at least this long.  Every repetition starts after an idle gap (barrier, synchronise,
+# events: ~0.1 ms), and for its first ~13 ms the device then runs ~1.7 % slower than in the long run (profiles/r04_launches_per_call.log: 800-2500 launches per call
+# 6.44-6.50 us each, 8000: 6.39, 20 000: 6.365): repetitions of 5 ms (rounds 2-4) measured mostly that recovery, and the driver's form (--steps 20) read 2 % lower
+# than the default form (--steps 1000) on every box.  100 ms repetitions report the sustained rate whatever K the command line names.
+MIN_REPETITION_SECONDS = 100e-3
 REPETITIONS = 9
 # Untimed stepping between the warm-up and the first timed repetition.  A process that has just started steps FASTER for its
 # first ~20 ms than it does in the long run (profiles/r03_slow_mode.log: 6.31 us per step 15 ms in, 6.46 from ~40 ms on, on
@@ -240,6 +244,8 @@ def parse_args(argv=None):
                     help="sum the statistics with torch.distributed instead of the C ABI's own RCCL communicator")
     ap.add_argument("--native-rccl", action="store_true", help="(default since round 2; kept for old command lines)")
     ap.add_argument("--repetitions", type=int, default=REPETITIONS)
+    ap.add_argument("--min-repetition-ms", type=float, default=MIN_REPETITION_SECONDS * 1e3,
+                    help="a timed repetition lasts at least this long (default 100: the sustained rate, see MIN_REPETITION_SECONDS; runs under a profiler use 5)")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-process copy-kernel probe (roofline.peak_measured)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configs (MountainCar 2^20, Pendulum 2^22, CartPole 2^24) that "
@@ -389,7 +395,7 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = Path(tmp) / ctr
             cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
-                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2"]
+                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2", "--min-repetition-ms", "5"]
             if args.n_envs:
                 cmd += ["--n-envs", str(args.n_envs)]
             if args.vec:
@@ -522,7 +528,7 @@ def run_rank(args, info, backend, make_collective=None):
             run_steps(args.steps * more)
             backend.sync()
             calibration_calls.append(args.steps * more)
-        passes = choose_passes(per_pass)
+        passes = choose_passes(per_pass, args.min_repetition_ms * 1e-3)
         settle_ms = (time.perf_counter() - t_settle) * 1e3
         if pinned:
             passes = max(1, int(pinned))

@@ -292,7 +292,8 @@ def test_launcher_pieces():
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-5:] == ["bench.py", "--gpus", "8", "--steps", "20"]
     import bench
 
-    assert bench.choose_passes(136e-6) == 37 and bench.choose_passes(0.02) == 1 and bench.choose_passes(0.0) == 1
+    assert bench.choose_passes(136e-6, 5e-3) == 37 and bench.choose_passes(0.02, 5e-3) == 1 and bench.choose_passes(0.0) == 1
+    assert bench.choose_passes(128e-6) * 128e-6 >= 0.1  # a repetition lasts >= 100 ms (profiles/r04_launches_per_call.log)
 
 
 def test_plain_multi_gpu_form_spawns_ranks_and_fails_loudly_without_gpus():

@@ -35,7 +35,7 @@ done
 # 4. kernel trace of the bench command (both call shapes run in it); the step kernels' (start, end) rows are kept as CSV
 cd /tmp
 rm -rf "$OUT/${TAG}_kt"
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -o r -- python "$REPO/bench.py" --steps 1000 --warmup 200 --cpu-seconds 0 --no-probe --no-configs \
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -o r -- python "$REPO/bench.py" --steps 1000 --warmup 200 --cpu-seconds 0 --no-probe --no-configs --min-repetition-ms 5 \
     > "$OUT/${TAG}_bench_cartpole_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"
 DB=$(find $OUT/${TAG}_kt -name '*_results.db' | head -1)
 python "$REPO/tools/summarize_rocprof.py" kernel "$DB" "$OUT/${TAG}_kernel_trace_stats_cartpole.txt" > /dev/null
