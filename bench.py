@@ -138,43 +138,41 @@ def load_free_running_traffic(config_name: str, path: str, sha: str):
     return rec, (None if rec else f"profiles/devcount_traffic.json has no entry for {config_name} / {path}")
 
 
-def roofline_of(path, n, bytes_per_step, launch_us, traffic_rec, traffic_note, kernel, sha, moved_bytes_per_step=None):
-    """The roofline object of one call shape.  per_step_visible: the contract's HBM roofline (algorithmic bytes / launch time / 8 TB/s; SURVEY
-    H1b: at 2^20 lanes the arrays pass through the Infinity Cache, so this is a fraction of the HBM ROOFLINE, not a claim about DRAM
-    traffic -- `traffic` says what the fabric saw).  chain: the state lives in the L2s between launches, so the bound that applies is
-    the L2s' bandwidth, and no HBM fraction is printed (VERDICT r3 "next" #1b)."""
-    achieved = n * bytes_per_step / (launch_us * 1e-6) / 1e9
-    # a chain is cache-resident while the fabric sees (far) less than the algorithmic bytes; where the figure is not on file: while one
-    # step's arrays fit the L2s and the Infinity Cache comfortably.  Beyond that a chain streams from HBM like any other launch.
-    # ("less" is judged against what the kernel moves by construction: MountainCar and Pendulum count bytes they never store)
-    moved = moved_bytes_per_step or bytes_per_step
-    resident = (traffic_rec["bytes_per_launch"] < 0.9 * n * moved) if traffic_rec else (n * bytes_per_step <= (128 << 20))
+def roofline_of(path, n, counted_bytes_per_step, launch_us, traffic_rec, traffic_note, kernel, sha, moved_bytes_per_step=None):
+    """The roofline object of one call shape on one leg.  ONE meaning per key, on every leg (VERDICT r4 "next" #2):
+      frac          bytes the kernel moves BY CONSTRUCTION per launch (MOVED_BYTES: 38 CartPole, 34 where its reward store is elided, 18 MountainCar,
+                    32.3 Pendulum) / launch time / peak -- = `achieved` / `peak`;
+      frac_counted  the contract's algorithmic bytes (SURVEY 8d: 38 / 22 / 37) / launch time / peak: credits bytes an engine never stores;
+      frac_moved    fabric bytes per launch seen by the device-wide counters (`traffic`, replayed from profiles/devcount_traffic.json: `traffic_from`)
+                    / launch time / 8 TB/s; null without a figure for exactly these kernel sources.
+    `peak` is the HBM roofline (8 TB/s) except for a cache-resident chain, whose state lives in the L2s between launches (`bound: "l2"`, 34.5 TB/s; no HBM
+    fraction is claimed for it).  `hbm_bound` says whether the fabric really moves (>= 0.9 x) the bytes of `frac`: false = part of a step's arrays is served
+    by the L2s / the Infinity Cache (`frac` is then a fraction of the HBM ROOFLINE, not HBM utilisation)."""
+    moved = moved_bytes_per_step or counted_bytes_per_step
+    seconds = launch_us * 1e-6
+    achieved = n * moved / seconds / 1e9
+    resident = (traffic_rec["bytes_per_launch"] < 0.9 * n * moved) if traffic_rec else (n * counted_bytes_per_step <= (128 << 20))
     in_l2 = path == "chain" and resident
     peak = L2_PEAK_GBPS if in_l2 else HBM_PEAK_GBPS
     roof = {"bound": "l2" if in_l2 else "hbm", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
-            "traffic": None, "kernel": kernel, "bytes_per_env_step": bytes_per_step, "bytes_per_launch": n * bytes_per_step,
-            "launch_us": launch_us, "kernel_source_sha16": sha}
-    if in_l2:
-        roof["bound_note"] = ("cache-resident: inside a chain the state is read out of the L2s (32 MiB, ~34.5 TB/s aggregate) and only write-backs and the "
-                              "streamed outputs cross the fabric, so the HBM roofline does not apply; the kernel is latency-bound (one generation of waves "
-                              "of ~3.4 us + a dependent launch), which is why `frac` of the L2s' bandwidth is low")
+            "frac_moved": None, "frac_counted": n * counted_bytes_per_step / seconds / 1e9 / peak,
+            "traffic": None, "kernel": kernel, "bytes_per_env_step": moved, "bytes_per_env_step_counted": counted_bytes_per_step,
+            "bytes_per_launch": n * moved, "launch_us": launch_us, "hbm_bound": (not resident) if traffic_rec else None, "kernel_source_sha16": sha}
     if traffic_rec:
         roof["traffic"] = traffic_rec["bytes_per_launch"]
+        roof["traffic_from"] = "file:profiles/devcount_traffic.json"  # a replay of a counter run on these kernel sources, not a measurement of this run
         roof["traffic_read"] = traffic_rec.get("fetch_bytes")
         roof["traffic_written"] = traffic_rec.get("write_bytes")
-        roof["traffic_source"] = "profiles/devcount_traffic.json: device-wide FETCH_SIZE / WRITE_SIZE around free-running launches of this call shape (same kernel sources)"
-        roof["traffic_over_algorithmic"] = traffic_rec["bytes_per_launch"] / (n * bytes_per_step)
-        roof["achieved_moved"] = traffic_rec["bytes_per_launch"] / (launch_us * 1e-6) / 1e9
-        roof["frac_moved"] = roof["achieved_moved"] / HBM_PEAK_GBPS
-        if not in_l2:
-            roof["hbm_bound"] = not resident
-            if not roof["hbm_bound"]:
-                roof["frac_note"] = ("the fabric sees %.2f x the algorithmic bytes: part of what a step reads is still in the L2s / the Infinity Cache from the step "
-                                     "before, so `frac` is a fraction of the HBM ROOFLINE (the contract's algorithmic bytes / time / 8 TB/s, SURVEY H1b), not HBM "
-                                     "utilisation; where every array streams from HBM see configs.cartpole_2p25_hbm_streaming" % roof["traffic_over_algorithmic"])
+        roof["traffic_over_bytes_by_construction"] = traffic_rec["bytes_per_launch"] / (n * moved)
+        roof["frac_moved"] = traffic_rec["bytes_per_launch"] / seconds / 1e9 / HBM_PEAK_GBPS
     elif traffic_note:
         roof["traffic_note"] = traffic_note
     return roof
+
+
+def moved_bytes(env_name: str, engine_extras: dict) -> float:
+    """Bytes per env-step this engine moves by construction: CartPole engines of >= 128 MiB per step do not rewrite their constant reward (the engine says so)."""
+    return MOVED_BYTES[env_name] - (4.0 if (env_name == "cartpole" and engine_extras.get("reward_store_elided")) else 0.0)
 
 
 def cpu_baseline(kind: int, target_seconds: float):
@@ -253,6 +251,7 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-traffic", action="store_true",
                     help="N=1: also run two short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) and "
                          "report the traffic they measure (and refresh profiles/pmc_traffic.json)")
+    ap.add_argument("--full-out", default="", help="where the complete record goes (default: bench_full.json next to this script); the printed line names it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: ranks share GPUs (rank r -> device r %% device_count) and meet over gloo, so that the "
                          "N>1 code path (spawner, global env offsets, aggregation) runs on a 1-GPU box; not a benchmark")
@@ -610,7 +609,7 @@ def run_rank(args, info, backend, make_collective=None):
                 prec["host_enqueue_us_per_step"] = {"min": min(t["enqueue_us"]), "median": statistics.median(t["enqueue_us"]), "max": max(t["enqueue_us"])}
             if per_step:
                 trec, tnote = load_free_running_traffic(config_name, path, sha) if config_name else (None, "no committed traffic figure for this size / tuning")
-                prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha, MOVED_BYTES[args.env])
+                prec["roofline"] = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, t["last_launch"], sha, moved_bytes(args.env, extras()))
                 prec["roofline"]["how"] = ("HIP events on the engine's stream around ONE gymrs_step_many(P*K) call / (P*K), median of the repetitions: the back-to-back "
                                            "launches with their gaps (for a chain also its hand-over from and back to the stream); rank 0's lanes")
             path_out[path] = prec
@@ -814,18 +813,12 @@ def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=Fals
             ex = json.loads(eng.env_json(0))["gymrs"]
         launch_us = statistics.median(us)
         trec, tnote = load_free_running_traffic(config_name, path, sha)
-        roof = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, ex.get("last_launch"), sha, MOVED_BYTES[env_name])
-        roof["frac_counted"], roof["achieved_counted"] = roof["frac"], roof["achieved"]
-        if trec and roof["bound"] == "hbm":  # first-class = what is moved
-            roof["achieved"], roof["frac"] = roof["achieved_moved"], roof["frac_moved"]
-            roof["frac_is"] = "fabric bytes of a free-running launch / launch time / 8 TB/s (what is MOVED); frac_counted = the contract's algorithmic bytes"
+        roof = roofline_of(path, n, bytes_per_step, launch_us, trec, tnote, ex.get("last_launch"), sha, moved_bytes(env_name, ex))
         prec = {"value": n / (launch_us * 1e-6), "unit": "env-steps/s", "launch_us": launch_us, "launch_us_min": us[0], "launch_us_max": us[-1],
                 "steps_per_repetition": n_pass * k, "roofline": roof,
                 "submission": ("chain" if ex.get("aql_launches", 0) > before else "HIP launches") if path == "chain" else "HIP launches"}
-        # CartPole engines of >= 128 MiB per step do not rewrite their constant reward (the engine says so): 4 of the 38 counted bytes are not moved
-        elided = 4 if (env_name == "cartpole" and ex.get("reward_store_elided")) else 0
-        if elided:
-            roof["reward_store_elided"] = "the engine elides CartPole's constant reward store at this size: 34 of the 38 counted bytes per env-step are moved; the copy floor copies 17 + 17"
+        elided = 4 if (env_name == "cartpole" and ex.get("reward_store_elided")) else 0  # (the copy floor then copies 17 + 17)
+        roof["reward_store_elided"] = bool(elided)
         if not no_probe:
             rd16, wr16 = n * bytes_read // 16 * 16, n * (bytes_written - elided) // 16 * 16
             base = 2 if path == "chain" else 0
@@ -841,6 +834,83 @@ def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=Fals
     rec.update({"value": hd["value"], "unit": "env-steps/s", "launch_us": hd["launch_us"], "launch_us_min": hd["launch_us_min"], "launch_us_max": hd["launch_us_max"],
                 "roofline": hd["roofline"], "call_shape": HEADLINE_PATH, "episodes_finished": float(stats[2])})
     return rec
+
+
+LINE_LIMIT = 4096  # bytes: the driver keeps the last 8 KB of stdout; round 4's 35 KB line came back as `parsed: null`
+
+
+def _sig(x, digits=6):
+    """Numbers of the printed line with 6 significant digits (the full record keeps every digit)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _roof_brief(r, keys=("bound", "achieved", "peak", "unit", "frac", "frac_moved", "frac_counted", "traffic", "kernel", "bytes_per_launch", "launch_us",
+                         "hbm_bound", "traffic_from", "frac_of_same_footprint_copy")):
+    return {k: (r[k][:120] if isinstance(r[k], str) else _sig(r[k])) for k in keys if k in r}
+
+
+def compact_line(out: dict, full_path) -> str:
+    """THE line (the last line of stdout): the contract's fields, the headline's roofline, the CPU baseline and one small record per other
+    call shape / BASELINE config -- numbers and names only, no prose.  Everything else (per-repetition times, per-rank records, notes, probes)
+    is in the full record `full` names (and on stderr)."""
+    line = {k: _sig(out[k]) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                      "dtype", "data") if k in out}
+    c = out.get("config", {})
+    line["config"] = {k: (c[k][:200] if isinstance(c[k], str) else c[k])
+                      for k in ("workload", "call_shape", "lanes_per_gpu", "total_lanes", "parallelism", "stats_allreduce", "steps_per_launch") if k in c}
+    if out.get("mode"):
+        line["mode"] = out["mode"]
+    t = out.get("timing", {})
+    if t:
+        line["timing"] = {"repetitions": t.get("repetitions"), "steps_per_repetition": t.get("steps_per_repetition"),
+                          "event_us_per_step": {k: _sig(v) for k, v in (t.get("event_us_per_step") or {}).items()}}
+    if "roofline" in out:
+        line["roofline"] = _roof_brief(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_moved", "frac_counted", "traffic", "kernel", "bytes_per_launch",
+                                                         "launch_us", "hbm_bound", "traffic_from", "frac_of_same_footprint_copy", "valu_instr_per_wave_step", "ns_per_lane_step"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb.get("sample_brief") or cb.get("sample", "")[:160]}
+        if cb.get("multi_thread"):
+            line["cpu_baseline"]["multi_thread"] = {"value": _sig(cb["multi_thread"]["value"]), "cores": cb["multi_thread"]["cores"]}
+    small = ("bound", "frac", "frac_moved", "frac_counted")
+    for name, p in (out.get("paths") or {}).items():
+        if name != c.get("call_shape"):
+            line.setdefault("paths", {})[name] = {"value": _sig(p["value"]), "launch_us": _sig(p["launch_us"]), **_roof_brief(p.get("roofline", {}), small)}
+    for name, cf in (out.get("configs") or {}).items():
+        line.setdefault("configs", {})[name] = {"value": _sig(cf["value"]), "launch_us": _sig(cf["launch_us"]), **_roof_brief(cf.get("roofline", {}), small)}
+    if "ranks" in out and out.get("n_gpus", 1) > 1:
+        line["ranks_launch_us"] = [_sig(r.get("launch_us"), 4) for r in out["ranks"]]
+        line["ranks_agree"] = out.get("ranks_agree")
+    for k in ("sharder", "oversubscribed"):
+        if k in out:
+            line[k] = out[k] if k == "sharder" else True
+    line["full"] = str(full_path) if full_path else None
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:  # never again a line the driver cannot keep: shed the optional blocks, largest first
+        for k in ("configs", "paths", "ranks_launch_us", "timing"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) <= LINE_LIMIT:
+                break
+    return text
+
+
+def write_full_record(out: dict, where) -> "Path | None":
+    """The complete record: to the file --full-out names (default bench_full.json next to this script; /tmp when the checkout is read-only)
+    and, pretty-printed, to stderr.  Returns the path that was written."""
+    text = json.dumps(out, indent=1)
+    sys.stderr.write("bench.py full record:\n" + text + "\n")
+    sys.stderr.flush()
+    for cand in ([Path(where)] if where else [ROOT / "bench_full.json", Path("/tmp") / f"gymrs_bench_full_{os.getpid()}.json"]):
+        try:
+            cand.write_text(text + "\n")
+            return cand
+        except OSError:
+            continue
+    return None
 
 
 def main(argv=None) -> int:
@@ -873,7 +943,8 @@ def main(argv=None) -> int:
         sys.stderr.flush()
         os._exit(3)
     if out is not None:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        full_path = write_full_record(out, args.full_out)
+        os.write(json_fd, (compact_line(out, full_path) + "\n").encode())
     os.close(json_fd)
     if getattr(args, "hard_exit", False):
         sys.stderr.flush()

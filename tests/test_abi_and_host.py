@@ -277,25 +277,79 @@ def test_library_embeds_the_chain_code_object_and_bench_names_its_kernels():
 
 
 def test_bench_rooflines_are_fractions_of_the_bound_that_applies():
-    """bench.roofline_of (host logic): the per-step-visible shape is held to the HBM roofline by the contract's algorithmic bytes; a chain is held
-    to the L2s while the fabric sees less than 0.9 x the algorithmic bytes (or nothing is on file and the arrays are small), to HBM beyond; the traffic
-    figure, where on file, gives frac_moved next to the counted fraction."""
+    """bench.roofline_of (host logic), ONE meaning per key on every leg (VERDICT r4 "next" #2): `frac` = bytes moved BY CONSTRUCTION / time / peak,
+    `frac_counted` = the contract's algorithmic bytes, `frac_moved` = fabric bytes of the counter file / time / 8 TB/s.  The per-step-visible shape is held
+    to the HBM roofline; a chain to the L2s while the fabric sees less than 0.9 x the bytes by construction (or nothing is on file and the arrays are small)."""
     import bench
 
     n, b = 1 << 20, 38
     vis = bench.roofline_of("per_step_visible", n, b, 6.4, {"bytes_per_launch": 26.1e6, "fetch_bytes": 4.4e6, "write_bytes": 21.7e6}, None, "k", "sha")
     assert vis["bound"] == "hbm" and vis["peak"] == 8000.0 and vis["frac"] == pytest.approx(n * b / 6.4e-6 / 1e9 / 8000.0) and vis["frac"] < 1.0
-    assert vis["traffic"] == 26.1e6 and vis["frac_moved"] == pytest.approx(26.1e6 / 6.4e-6 / 1e9 / 8000.0) and vis["hbm_bound"] is False and "frac_note" in vis
+    assert vis["frac_counted"] == vis["frac"] and vis["achieved"] == pytest.approx(vis["bytes_per_launch"] / 6.4e-6 / 1e9)
+    assert vis["traffic"] == 26.1e6 and vis["frac_moved"] == pytest.approx(26.1e6 / 6.4e-6 / 1e9 / 8000.0) and vis["hbm_bound"] is False
+    assert vis["traffic_from"].startswith("file:profiles/")  # a replay of a counter run, not a measurement of this run (VERDICT r4 weak #6)
     ch = bench.roofline_of("chain", n, b, 4.9, {"bytes_per_launch": 18.5e6}, None, "k", "sha")
-    assert ch["bound"] == "l2" and ch["peak"] == 34500.0 and 0 < ch["frac"] < 1.0 and "bound_note" in ch and "hbm_bound" not in ch
+    assert ch["bound"] == "l2" and ch["peak"] == 34500.0 and 0 < ch["frac"] < 1.0 and ch["hbm_bound"] is False
+    assert ch["frac_moved"] == pytest.approx(18.5e6 / 4.9e-6 / 1e9 / 8000.0)  # always against HBM: the fabric is what it crosses
     big = bench.roofline_of("chain", 1 << 24, b, 99.0, {"bytes_per_launch": 660e6}, None, "k", "sha")
     assert big["bound"] == "hbm" and big["hbm_bound"] is True and big["frac"] < 1.0
     nofile = bench.roofline_of("chain", n, b, 4.9, None, "why", "k", "sha")
-    assert nofile["bound"] == "l2" and nofile["traffic"] is None and nofile["traffic_note"] == "why"
+    assert nofile["bound"] == "l2" and nofile["traffic"] is None and nofile["frac_moved"] is None and nofile["hbm_bound"] is None and nofile["traffic_note"] == "why"
     assert bench.roofline_of("chain", 1 << 24, b, 99.0, None, "why", "k", "sha")["bound"] == "hbm"
+    # the 2^24-lane CartPole leg with its reward store elided: 34 B by construction -> frac 0.81, counters -> 0.85, the contract's 38 -> 0.91
+    # (the three figures VERDICT r4 weak #5 recomputed from profiles/r04_*)
+    el = bench.roofline_of("per_step_visible", 1 << 24, 38, 87.96, {"bytes_per_launch": 595.2e6}, None, "k", "sha", bench.moved_bytes("cartpole", {"reward_store_elided": True}))
+    assert el["bytes_per_env_step"] == 34.0 and el["bytes_per_env_step_counted"] == 38
+    assert (round(el["frac"], 2), round(el["frac_moved"], 2), round(el["frac_counted"], 2)) == (0.81, 0.85, 0.91) and el["hbm_bound"] is True
     # Pendulum counts 37 B per env-step and moves ~32.3 by construction: 0.875 x the algorithmic bytes on the fabric is NOT cache residency
     pend = bench.roofline_of("chain", 1 << 22, 37, 23.0, {"bytes_per_launch": 135.6e6}, None, "k", "sha", bench.MOVED_BYTES["pendulum"])
-    assert pend["bound"] == "hbm" and pend["hbm_bound"] is True
+    assert pend["bound"] == "hbm" and pend["hbm_bound"] is True and pend["frac"] < pend["frac_counted"]
+    mc = bench.roofline_of("per_step_visible", n, 22, 4.1, None, "why", "k", "sha", bench.MOVED_BYTES["mountain_car"])
+    assert mc["frac"] == pytest.approx(n * 18 / 4.1e-6 / 1e9 / 8000.0) and mc["frac_counted"] == pytest.approx(n * 22 / 4.1e-6 / 1e9 / 8000.0)
+
+
+def test_bench_prints_a_line_the_driver_can_keep(tmp_path):
+    """bench.compact_line: the LAST stdout line stays under 4 KB whatever the full record holds (round 4's 35 KB line came back from the driver as
+    `parsed: null`); it carries the contract's fields, `roofline` and `cpu_baseline`, small per-config records and the path of the full record."""
+    import json
+
+    import bench
+
+    roof = bench.roofline_of("per_step_visible", 1 << 20, 38, 6.4, {"bytes_per_launch": 26.1e6, "fetch_bytes": 4.4e6, "write_bytes": 21.7e6}, None,
+                             "HIP launch: gymrs::step_kernel<CartPoleT, 4, flags 3 | hint nt, 512 work-items>", "sha")
+    roof["how"] = "prose " * 200
+    path_rec = {"value": 1.6e11, "launch_us": 6.4, "roofline": roof, "what": "x" * 500, "wall_ms_per_repetition": [1.0] * 9}
+    full = {"metric": "env-steps/sec (whole node), CartPole-v1 @ 2^20 envs per MI355X", "value": 163840000000.12345, "unit": "env-steps/s", "n_gpus": 8, "steps": 20,
+            "warmup": 5, "ms_per_step": 0.0064000001, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CartPole-v1 @ 2^20 envs per GPU, f32, auto-reset, random policy", "call_shape": "per_step_visible", "lanes_per_gpu": 1 << 20,
+                       "total_lanes": 8 << 20, "call_shape_note": "y" * 400, "parallelism": "lane-sharded x8"},
+            "timing": {"repetitions": 9, "steps_per_repetition": 16000, "event_us_per_step": {"min": 6.3, "median": 6.4, "max": 6.5, "spread": 0.03},
+                       "wall_ms_per_repetition": [100.0] * 9},
+            "roofline": roof, "paths": {"per_step_visible": path_rec, "chain": dict(path_rec, roofline=bench.roofline_of("chain", 1 << 20, 38, 4.9, None, "n", "k", "sha"))},
+            "configs": {name: {"value": 1e11, "launch_us": 88.0, "roofline": roof, "paths": {"per_step_visible": path_rec, "chain": path_rec}} for name in bench.EXTRA_CONFIGS},
+            "ranks": [{"rank": r, "launch_us": 6.4, "paths": {"a": "z" * 300}} for r in range(8)], "ranks_agree": True,
+            "cpu_baseline": {"value": 5.65e7, "unit": "env-steps/s", "cores": 1, "kind": "port", "sample": "s" * 400, "multi_thread": {"value": 8.6e8, "cores": 16, "sample": "t" * 300}}}
+    assert len(json.dumps(full)) > 20000
+    where = bench.write_full_record(full, str(tmp_path / "full.json"))
+    assert json.loads(where.read_text()) == full
+    text = bench.compact_line(full, where)
+    assert "\n" not in text and len(text) <= 2600 < bench.LINE_LIMIT, len(text)
+    line = json.loads(text)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline", "full"):
+        assert key in line, key
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5) and line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    for key in ("bound", "achieved", "peak", "unit", "frac", "frac_moved", "frac_counted", "traffic", "kernel", "bytes_per_launch", "launch_us", "hbm_bound", "traffic_from"):
+        assert key in line["roofline"], key
+    assert line["roofline"]["frac"] == pytest.approx(roof["frac"], rel=1e-5) and "how" not in line["roofline"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1 and len(line["cpu_baseline"]["sample"]) <= 160
+    assert set(line["configs"]) == set(bench.EXTRA_CONFIGS) and set(line["paths"]) == {"chain"}
+    assert set(line["configs"]["mountain_car_2p20"]) == {"value", "launch_us", "bound", "frac", "frac_moved", "frac_counted"}
+    assert line["config"]["workload"] == full["config"]["workload"] and "model" not in line["config"] and line["full"] == str(where)
+    # a record that would still be too long sheds its optional blocks instead of growing past the limit
+    full["config"]["workload"] = "w" * 3000
+    fat = bench.compact_line(full, where)
+    assert len(fat) <= bench.LINE_LIMIT and "roofline" in json.loads(fat) and "cpu_baseline" in json.loads(fat)
 
 
 def test_committed_traffic_files_cover_both_call_shapes():
