@@ -37,6 +37,7 @@ from __future__ import annotations
 import argparse
 import hashlib
 import importlib
+import importlib.util
 import json
 import math
 import os
@@ -316,12 +317,12 @@ class HipBackend:
         self.torch.cuda.synchronize()
 
     def copy_probe(self, read_bytes, write_bytes, launches, nt):
-        import ctypes as C
-
-        lib = self.gymrs.load_library()
-        out = C.c_double()
-        st = lib.gymrs_copy_probe(self.dev_index, int(read_bytes), int(write_bytes), int(launches), int(nt), C.byref(out))
-        return out.value if st == 0 else None
+        """The copy yardstick: tools/copy_probe (a measurement tool, not part of the C ABI), loaded with ctypes."""
+        if getattr(self, "_probe", None) is None:
+            spec = importlib.util.spec_from_file_location("gymrs_copy_probe_tool", ROOT / "tools" / "copy_probe" / "build.py")
+            self._probe = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(self._probe)
+        return self._probe.copy_probe(self.dev_index, read_bytes, write_bytes, launches, nt)
 
     def trajectory_buffers(self, eng, n, rollout, is_float):
         torch = self.torch

@@ -1,9 +1,15 @@
-//! Raw declarations of `include/gymrs_amd.h` (ABI version 2).  Field order and types follow the header.
+//! Raw declarations of `include/gymrs_amd.h` (ABI version 3).  Field order and types follow the header.
 #![allow(missing_docs)]
 use std::os::raw::{c_char, c_int, c_void};
 
 #[repr(C)]
 pub struct GymrsEngine {
+    _opaque: [u8; 0],
+}
+
+/// `gymrs_sharded`: one batch over several GPUs in one process.
+#[repr(C)]
+pub struct GymrsSharded {
     _opaque: [u8; 0],
 }
 
@@ -119,4 +125,43 @@ extern "C" {
     pub fn gymrs_get_params(e: *mut GymrsEngine, params_out: *mut c_void) -> c_int;
     pub fn gymrs_env_json(e: *mut GymrsEngine, lane: u64, buf: *mut c_char, cap: u64, needed: *mut u64) -> c_int;
     pub fn gymrs_params_from_json(kind: c_int, json: *const c_char, params: *mut c_void, state: *mut f64, state_dim: *mut c_int) -> c_int;
+    // ABI 3: one batch over several GPUs in ONE process (one engine + one native host thread per block)
+    pub fn gymrs_allreduce_stats_multi(shards: *mut *mut GymrsEngine, n: c_int, out4: *mut f64, used_rccl: *mut c_int) -> c_int;
+    pub fn gymrs_sharded_create(
+        kind: c_int,
+        n_total: u64,
+        global_env_offset: u64,
+        n_shards: c_int,
+        devices: *const c_int,
+        params: *const c_void,
+        flags: u32,
+        out: *mut *mut GymrsSharded,
+    ) -> c_int;
+    pub fn gymrs_sharded_destroy(h: *mut GymrsSharded) -> c_int;
+    pub fn gymrs_sharded_count(h: *mut GymrsSharded, n_shards: *mut c_int) -> c_int;
+    pub fn gymrs_sharded_shard(
+        h: *mut GymrsSharded,
+        shard: c_int,
+        engine: *mut *mut GymrsEngine,
+        first_lane: *mut u64,
+        n_lanes: *mut u64,
+        device: *mut c_int,
+    ) -> c_int;
+    pub fn gymrs_sharded_reset(h: *mut GymrsSharded, has_seed: c_int, seed: u64, bounds_low_high: *const f32, seed_used: *mut u64) -> c_int;
+    pub fn gymrs_sharded_step(h: *mut GymrsSharded, actions_dev: *const *const c_void) -> c_int;
+    pub fn gymrs_sharded_step_many(
+        h: *mut GymrsSharded,
+        actions_dev: *const *const c_void,
+        stride_bytes: u64,
+        n_buffers: u32,
+        n_steps: u32,
+        use_graph: c_int,
+    ) -> c_int;
+    pub fn gymrs_sharded_fill_actions(h: *mut GymrsSharded, actions_dev: *const *mut c_void, seed: u64, t: u64) -> c_int;
+    pub fn gymrs_sharded_sync(h: *mut GymrsSharded) -> c_int;
+    pub fn gymrs_sharded_stats(h: *mut GymrsSharded, out4: *mut f64) -> c_int;
+    pub fn gymrs_sharded_stats_clear(h: *mut GymrsSharded) -> c_int;
+    pub fn gymrs_sharded_reduce_path(h: *mut GymrsSharded) -> *const c_char;
+    pub fn gymrs_sharded_get_state(h: *mut GymrsSharded, first: u64, count: u64, host_out: *mut f32) -> c_int;
+    pub fn gymrs_sharded_get_step_result(h: *mut GymrsSharded, first: u64, count: u64, reward: *mut f32, done: *mut u8, truncated: *mut u8) -> c_int;
 }

@@ -5,6 +5,7 @@
 //!   `examples/*.rs`; no faster than the CPU crate (a step is a kernel launch plus two small copies).
 //! * [`engine::Engine`]: the batched stepper itself -- millions of lanes per GPU, `step_device`, `rollout`,
 //!   `stats`, `clone`, `snapshot` -- which is what the C ABI is built for.
+//! * [`sharded::ShardedEngine`]: one batch over the GPUs of a node in one process (one engine and one native host thread per block).
 //!
 //! Deviation: `EnvProperties::rand_random` returns a `Pcg64` that only mirrors the seed; the device samples
 //! with counter-based Philox4x32-10 (state = seed + tick).
@@ -13,3 +14,4 @@ pub mod cartpole;
 pub mod engine;
 pub mod ffi;
 pub mod mountain_car;
+pub mod sharded;

@@ -28,6 +28,7 @@ from .engine import (
     InvalidActionError,
     MountainCarParams,
     PendulumParams,
+    ShardedEngine,
     shard_range,
 )
 from .envs import (
@@ -48,5 +49,5 @@ __all__ = [
     "CartPoleParams", "MountainCarParams", "PendulumParams", "CartPoleEnv", "MountainCarEnv", "PendulumEnv",
     "CartPoleObservation", "MountainCarObservation", "PendulumObservation", "RenderMode",
     "AUTO_RESET", "TRACK_STATS", "TIME_LIMIT", "CARTPOLE", "MOUNTAIN_CAR", "PENDULUM",
-    "library_path", "load_library", "shard_range", "sharded", "params_from_json",
+    "library_path", "load_library", "shard_range", "ShardedEngine", "sharded", "params_from_json",
 ]

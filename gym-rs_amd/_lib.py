@@ -9,7 +9,7 @@ import os
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
-ABI_VERSION = 2  # GYMRS_ABI_VERSION of include/gymrs_amd.h
+ABI_VERSION = 3  # GYMRS_ABI_VERSION of include/gymrs_amd.h
 _LIB = None
 
 u8p = C.POINTER(C.c_uint8)
@@ -61,7 +61,22 @@ SIGNATURES = {
     "gymrs_get_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gymrs_env_json": (C.c_int, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_uint64, u64p]),
     "gymrs_params_from_json": (C.c_int, [C.c_int, C.c_char_p, C.c_void_p, f64p, C.POINTER(C.c_int)]),
-    "gymrs_copy_probe": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, f64p]),
+    # one batch over several GPUs in one process
+    "gymrs_allreduce_stats_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, f64p, C.POINTER(C.c_int)]),
+    "gymrs_sharded_create": (C.c_int, [C.c_int, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "gymrs_sharded_destroy": (C.c_int, [C.c_void_p]),
+    "gymrs_sharded_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "gymrs_sharded_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), u64p, u64p, C.POINTER(C.c_int)]),
+    "gymrs_sharded_reset": (C.c_int, [C.c_void_p, C.c_int, C.c_uint64, f32p, u64p]),
+    "gymrs_sharded_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "gymrs_sharded_step_many": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
+    "gymrs_sharded_fill_actions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64]),
+    "gymrs_sharded_sync": (C.c_int, [C.c_void_p]),
+    "gymrs_sharded_stats": (C.c_int, [C.c_void_p, f64p]),
+    "gymrs_sharded_stats_clear": (C.c_int, [C.c_void_p]),
+    "gymrs_sharded_reduce_path": (C.c_char_p, [C.c_void_p]),
+    "gymrs_sharded_get_state": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "gymrs_sharded_get_step_result": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gymrs_last_error": (C.c_char_p, []),
     "gymrs_abi_version": (C.c_int, []),
 }

@@ -22,8 +22,8 @@ CSRC = PKG / "csrc"
 ORACLE = ROOT / "oracle"
 
 HIP_SOURCES = [CSRC / "gymrs_step_cartpole.hip", CSRC / "gymrs_step_mountain_car.hip", CSRC / "gymrs_step_pendulum.hip",
-               CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip", CSRC / "gymrs_engine_io.hip", CSRC / "gymrs_probe.hip",
-               CSRC / "gymrs_aql.hip"]
+               CSRC / "gymrs_rollout.hip", CSRC / "gymrs_aux.hip", CSRC / "gymrs_engine.hip", CSRC / "gymrs_engine_io.hip",
+               CSRC / "gymrs_aql.hip", CSRC / "gymrs_sharded.hip"]
 # The per-step kernels once more as a stand-alone gfx950 code object (device-only compile), embedded into the library by
 # gymrs_aql.hip (.incbin) and loaded through HSA by the engine's own AQL dispatcher.
 AQL_KERNELS = CSRC / "gymrs_step_aql.hip"

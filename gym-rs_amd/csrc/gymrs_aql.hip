@@ -280,6 +280,21 @@ public:
 
 namespace {
 
+// One kernel of the loaded code object by name -> c->kernels (the caller holds g_mu or is the only user of c).
+bool lookup_kernel(DeviceCtx* c, const std::string& name, std::string* why)
+{
+    const char* nm = name.c_str();
+    hsa_executable_symbol_t sym;
+    HSA_OK(hsa_executable_get_symbol_by_name(c->exe, (name + ".kd").c_str(), &c->gpu, &sym), nm);
+    AqlKernel k;
+    HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object), nm);
+    HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_bytes), nm);
+    HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_bytes), nm);
+    HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_bytes), nm);
+    c->kernels[name] = k;
+    return true;
+}
+
 bool load_code(DeviceCtx* c, std::string* why)
 {
 #if !defined(__HIP_DEVICE_COMPILE__)
@@ -289,7 +304,8 @@ bool load_code(DeviceCtx* c, std::string* why)
     HSA_OK(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe), "hsa_executable_create_alt");
     HSA_OK(hsa_executable_load_agent_code_object(c->exe, c->gpu, reader, nullptr, nullptr), "loading the AQL code object");
     HSA_OK(hsa_executable_freeze(c->exe, nullptr), "hsa_executable_freeze");
-    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck", "gymrs_aql_copy_probe_pl", "gymrs_aql_copy_probe_nt", "gymrs_aql_copy_probe_st", "gymrs_aql_copy_probe_pl1", "gymrs_aql_copy_probe_nt1", "gymrs_aql_copy_probe_st1"};
+    std::vector<std::string> names = {"gymrs_aql_wait_flag", "gymrs_aql_set_flag", "gymrs_aql_selfcheck"};
+#ifndef GYMRS_AQL_ENDS_ONLY // (a tool's build of the dispatcher against its own code object: its kernels are looked up when asked for, aql_kernel)
     for (const char* env_threads : {"cartpole_f%d_t512", "cartpole_f%d_t256", "mountain_car_f%d_t256", "pendulum_f%d_t256"}) // (gymrs_step_aql.hip)
         for (int flags : {0, 1, 3, 4, 5, 7})
             for (const char* hint : {"_nt", "_o", "_so", "_pl"}) {
@@ -297,17 +313,9 @@ bool load_code(DeviceCtx* c, std::string* why)
                 std::snprintf(stem, sizeof(stem), env_threads, flags);
                 names.push_back(std::string("gymrs_aql_") + stem + hint);
             }
-    for (const std::string& name : names) {
-        const char* nm = name.c_str();
-        hsa_executable_symbol_t sym;
-        HSA_OK(hsa_executable_get_symbol_by_name(c->exe, (name + ".kd").c_str(), &c->gpu, &sym), nm);
-        AqlKernel k;
-        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &k.object), nm);
-        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &k.kernarg_bytes), nm);
-        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &k.group_bytes), nm);
-        HSA_OK(hsa_executable_symbol_get_info(sym, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &k.private_bytes), nm);
-        c->kernels[nm] = k;
-    }
+#endif
+    for (const std::string& name : names)
+        if (!lookup_kernel(c, name, why)) return false;
     return true;
 #else
     (void)c;
@@ -646,8 +654,13 @@ void aql_destroy(AqlChain* c)
 
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out)
 {
+    std::lock_guard<std::mutex> lock(g_mu); // (engines of one device may ask from different threads: the in-process sharder's workers)
     auto it = c->ctx->kernels.find(name);
-    if (it == c->ctx->kernels.end()) return false;
+    if (it == c->ctx->kernels.end()) { // not one of the names checked when the code object was loaded: look it up now
+        std::string why;
+        if (!lookup_kernel(c->ctx, name, &why)) return false;
+        it = c->ctx->kernels.find(name);
+    }
     *out = it->second;
     return true;
 }

@@ -386,41 +386,6 @@ hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, ui
     return hipGetLastError();
 }
 
-// gymrs_copy_probe (measurement): the plain copy a step launch of the same size is compared with (copy_probe_body,
-// gymrs_tile.h).  Two shapes: at a step's footprint a work-item moves 4 items like the step kernel's tiles; from 1.5 GiB per launch on
-// (the HBM figure: 1 GiB + 1 GiB) one item per work-item -- measured on MI355X (profiles/r04_hbm_probe.log): 6.61 TB/s against 6.24 for the 4-item
-// shape and 5.9-6.1 for every persistent grid-stride form; the guide's own float4 copy reads 6.29.
-template <bool NTL, bool NTS, int ITEMS>
-__global__ __launch_bounds__(kBlock) void copy_probe_kernel(const uint32_t* src, uint64_t n_read16, uint32_t* dst,
-                                                            uint64_t n_write16)
-{
-    copy_probe_body<NTL, NTS, ITEMS>(src, n_read16, dst, n_write16);
-}
-
-// hint: 0 none, 1 loads and stores non-temporal, 2 stores only; items: 16-byte items per work-item (kCopyProbeItems, or 1)
-hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, int items_per_thread, hipStream_t stream)
-{
-    const uint64_t items = n_read16 > n_write16 ? n_read16 : n_write16;
-    if (items == 0) return hipSuccess;
-    const bool one = items_per_thread == 1;
-    const uint64_t per_block = (uint64_t)kBlock * (one ? 1 : kCopyProbeItems);
-    const uint64_t grid = (items + per_block - 1) / per_block;
-    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const uint32_t* s = static_cast<const uint32_t*>(src);
-    uint32_t* d = static_cast<uint32_t*>(dst);
-    const dim3 g((uint32_t)grid), b(kBlock);
-#define GYMRS_COPY_LAUNCH(NTL_, NTS_)                                                                                                  \
-    do {                                                                                                                               \
-        if (one) hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, 1>), g, b, 0, stream, s, n_read16, d, n_write16);                   \
-        else hipLaunchKernelGGL((copy_probe_kernel<NTL_, NTS_, kCopyProbeItems>), g, b, 0, stream, s, n_read16, d, n_write16);         \
-    } while (0)
-    if (hint == 1) GYMRS_COPY_LAUNCH(true, true);
-    else if (hint == 2) GYMRS_COPY_LAUNCH(false, true);
-    else GYMRS_COPY_LAUNCH(false, false);
-#undef GYMRS_COPY_LAUNCH
-    return hipGetLastError();
-}
-
 // the per-step kernel tables live in one translation unit per env type
 hipError_t launch_step_cartpole(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);
 hipError_t launch_step_mountain_car(int vec, uint32_t flags, const StepArgs& a, const void* consts, hipStream_t stream);

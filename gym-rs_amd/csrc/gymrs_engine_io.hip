@@ -399,6 +399,8 @@ static gymrs_status rccl_load()
     api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(dlsym(lib, "ncclAllReduce"));
     api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
     api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
     if (!api.GetUniqueId || !api.CommInitRank || !api.AllReduce || !api.CommDestroy)
         return fail(GYMRS_ENCCL, "librccl lacks an expected nccl* symbol");
     g_rccl = api;
@@ -426,8 +428,10 @@ gymrs_status gymrs_comm_init(gymrs_engine* e, int n_ranks, int rank, const uint8
     HIP_TRY(hipSetDevice(e->device));
     NcclId128 uid;
     std::memcpy(uid.internal, id, 128);
+    comm_destroy(e); // (a communicator of an earlier call, e.g. the in-process sharder's)
     if (int rc = g_rccl.CommInitRank(&e->comm, n_ranks, uid, rank)) return nccl_fail("ncclCommInitRank", rc);
     e->n_ranks = n_ranks;
+    e->comm_rank = rank;
     return GYMRS_OK;
 }
 
@@ -441,6 +445,83 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4])
     if (int rc = g_rccl.AllReduce(dev, dev, 4, 8, 0, e->comm, e->stream)) return nccl_fail("ncclAllReduce", rc);
     HIP_TRY(hipMemcpyAsync(out, dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    return GYMRS_OK;
+}
+
+// The in-process form (`gymrs_allreduce_stats(gymrs_engine** shards, int n, double out[4])`): ONE host thread holds every shard of a
+// batch, one engine per GPU.  On distinct devices the sum is an RCCL all-reduce over xGMI: the communicators are made once, all ranks in one
+// ncclGroupStart / ncclGroupEnd (what ncclCommInitAll does; a bare ncclCommInitRank per engine from one thread would wait for the other ranks
+// for ever), and every later call issues the n all-reduces of 32 bytes inside one group, each on its engine's stream.  Where two shards share
+// a device RCCL refuses the communicator ("duplicate GPU"), and nothing has to cross a link: the same four doubles are summed on the host.
+// Either way every engine's statistics read-out runs on its own stream first and `out` holds the batch's totals when the call returns.
+gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl)
+{
+    if (!shards || n < 1 || !out) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats_multi: NULL argument or n < 1");
+    if (used_rccl) *used_rccl = 0;
+    bool distinct = true;
+    for (int r = 0; r < n; ++r) {
+        if (!shards[r]) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats_multi: a shard is NULL");
+        for (int q = 0; q < r; ++q) {
+            if (shards[q] == shards[r]) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats_multi: the same engine appears twice");
+            distinct = distinct && shards[q]->device != shards[r]->device;
+        }
+    }
+    if (n == 1 || !distinct) { // host-side sum: same interface, no link to cross
+        double total[4] = {0, 0, 0, 0};
+        std::vector<double*> dev((size_t)n);
+        for (int r = 0; r < n; ++r) // every read-out kernel is enqueued before the first wait
+            if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
+        for (int r = 0; r < n; ++r) {
+            HIP_TRY(hipSetDevice(shards[r]->device));
+            HIP_TRY(hipStreamSynchronize(shards[r]->stream));
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (int j = 0; j < 4; ++j) total[j] += shards[r]->stats_host[j];
+        }
+        for (int j = 0; j < 4; ++j) out[j] = total[j];
+        return GYMRS_OK;
+    }
+    if (gymrs_status st = rccl_load()) return st;
+    if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(GYMRS_ENCCL, "librccl lacks ncclGroupStart / ncclGroupEnd");
+    bool have = true;
+    for (int r = 0; r < n; ++r) have = have && shards[r]->comm && shards[r]->n_ranks == n && shards[r]->comm_rank == r;
+    if (!have) { // first call for this set of shards (or another set before): one communicator over exactly these engines, rank = index
+        for (int r = 0; r < n; ++r) comm_destroy(shards[r]);
+        NcclId128 uid;
+        if (int rc = g_rccl.GetUniqueId(&uid)) return nccl_fail("ncclGetUniqueId", rc);
+        if (int rc = g_rccl.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+        int bad = 0;
+        for (int r = 0; r < n && !bad; ++r) {
+            HIP_TRY(hipSetDevice(shards[r]->device));
+            bad = g_rccl.CommInitRank(&shards[r]->comm, n, uid, r);
+        }
+        const int end = g_rccl.GroupEnd();
+        if (bad || end) {
+            for (int r = 0; r < n; ++r) shards[r]->comm = nullptr; // (a communicator of a failed group is not one to destroy)
+            return nccl_fail("ncclCommInitRank (grouped, one rank per device)", bad ? bad : end);
+        }
+        for (int r = 0; r < n; ++r) {
+            shards[r]->n_ranks = n;
+            shards[r]->comm_rank = r;
+        }
+    }
+    std::vector<double*> dev((size_t)n);
+    for (int r = 0; r < n; ++r)
+        if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
+    if (int rc = g_rccl.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+    int bad = 0;
+    for (int r = 0; r < n && !bad; ++r) {
+        HIP_TRY(hipSetDevice(shards[r]->device));
+        bad = g_rccl.AllReduce(dev[(size_t)r], dev[(size_t)r], 4, 8 /* ncclFloat64 */, 0 /* ncclSum */, shards[r]->comm, shards[r]->stream);
+    }
+    const int end = g_rccl.GroupEnd();
+    if (bad || end) return nccl_fail("ncclAllReduce (grouped)", bad ? bad : end);
+    HIP_TRY(hipSetDevice(shards[0]->device));
+    HIP_TRY(hipMemcpyAsync(out, dev[0], 4 * sizeof(double), hipMemcpyDeviceToHost, shards[0]->stream));
+    for (int r = 0; r < n; ++r) { // every rank's copy of the sum is complete when the call returns
+        HIP_TRY(hipSetDevice(shards[r]->device));
+        HIP_TRY(hipStreamSynchronize(shards[r]->stream));
+    }
+    if (used_rccl) *used_rccl = 1;
     return GYMRS_OK;
 }
 

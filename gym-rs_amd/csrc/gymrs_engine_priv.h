@@ -49,6 +49,8 @@ struct RcclApi {
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr; // several devices driven by ONE thread (gymrs_allreduce_stats_multi): RCCL's calls are collective per
+    int (*GroupEnd)() = nullptr;   // communicator, so one thread may only issue them for all of its devices inside a group
 };
 
 struct gymrs_engine {
@@ -129,7 +131,7 @@ struct gymrs_engine {
     uint64_t graph_seed = 0;
     unsigned long long* tick_dev = nullptr;
     void* comm = nullptr; // ncclComm_t
-    int n_ranks = 1;
+    int n_ranks = 1, comm_rank = 0;
     // GYMRS_TIME_LIMIT elision (CartPole with all three flags): a launch whose tick cannot take any lane to the limit runs
     // the kernel WITHOUT the limit -- the reset-logged headline kernel -- and the `truncated` array stays all zero.  start_bound = a tick no open episode started before (ep_start only grows, so a
     // stale bound stays valid); refreshed asynchronously from the age of the oldest open episode (max_age_kernel).

@@ -196,16 +196,4 @@ hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
 // device words of scratch; the result goes to host_out2 (device-visible host memory): [0] = the age, then [1] = seq.
 hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
                           hipStream_t stream);
-// gymrs_copy_probe: reads n_read16 and writes n_write16 16-byte items; kCopyProbeItems items per work-item or one (the caller's choice;
-// always one from kCopyProbeBigBytes per launch on: gymrs_aux.hip says why)
-constexpr int kCopyProbeItems = 4;
-constexpr uint64_t kCopyProbeBigBytes = 1536ull << 20;
-struct CopyProbeKernArgs { // the kernel-argument segment of the copy probe's kernels as the engine's own dispatcher fills it
-    const uint32_t* src;
-    uint64_t n_read16;
-    uint32_t* dst;
-    uint64_t n_write16;
-};
-hipError_t launch_copy_probe(const void* src, uint64_t n_read16, void* dst, uint64_t n_write16, int hint, int items_per_thread, hipStream_t stream);
-
 } // namespace gymrs

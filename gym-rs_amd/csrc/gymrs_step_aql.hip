@@ -8,9 +8,13 @@
 // Every flag set of the launch table at 4 lanes per work-item (8 lanes per work-item is a tuning knob and stays on HIP launches), named
 //   gymrs_aql_<env>_f<AUTO_RESET | TRACK_STATS | TIME_LIMIT as a number>_t<work-items per workgroup>_<hint variant>
 // (TRACK_STATS without AUTO_RESET does not exist: the launch table drops it, and so does the engine before it asks for a name).
+// GYMRS_AQL_ENDS_ONLY: only the chain's two ends and the self-check -- what the dispatcher needs in WHATEVER code object it loads (tools/copy_probe
+// compiles the dispatcher against a code object of its own: these three kernels plus its copy kernels).
 #include "gymrs_step_impl.h"
 
 using namespace gymrs;
+
+#ifndef GYMRS_AQL_ENDS_ONLY
 
 #define GYMRS_AQL_STEP(NAME_, ENV_, FLAGS_, THREADS_)                                                                                     \
     extern "C" GYMRS_STEP_KERNEL_ATTRS(THREADS_, 4) void NAME_(float* s0, float* s1, float* s2, float* s3, const void* action,           \
@@ -37,20 +41,7 @@ GYMRS_AQL_STEP_FLAGSETS(cartpole, CartPoleT, 512)
 GYMRS_AQL_STEP_FLAGSETS(cartpole, CartPoleT, 256)
 GYMRS_AQL_STEP_FLAGSETS(mountain_car, MountainCarT, 256)
 GYMRS_AQL_STEP_FLAGSETS(pendulum, PendulumT, 256)
-
-// ---- the copy probe's kernel (gymrs_copy_probe through a chain: the floor a chain's step is compared with) ---------------------
-#define GYMRS_AQL_COPY(NAME_, NTL_, NTS_)                                                                                                       \
-    extern "C" __global__ __launch_bounds__(kBlock) void NAME_(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)       \
-    {                                                                                                                                         \
-        copy_probe_body<NTL_, NTS_, kCopyProbeItems>(src, n_read16, dst, n_write16);                                                          \
-    }                                                                                                                                         \
-    extern "C" __global__ __launch_bounds__(kBlock) void NAME_##1(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16)    \
-    {                                                                                                                                         \
-        copy_probe_body<NTL_, NTS_, 1>(src, n_read16, dst, n_write16); /* one item per work-item */                                           \
-    }
-GYMRS_AQL_COPY(gymrs_aql_copy_probe_pl, false, false) // hints: none
-GYMRS_AQL_COPY(gymrs_aql_copy_probe_nt, true, true)   // loads and stores
-GYMRS_AQL_COPY(gymrs_aql_copy_probe_st, false, true)  // stores only
+#endif // GYMRS_AQL_ENDS_ONLY
 
 // ---- the two ends of a chain: ordering against the engine's HIP stream -------------------------------------------------
 // First packet of a chain: one wavefront waits until the HIP stream has reached the hipStreamWriteValue32 the engine put

@@ -110,35 +110,6 @@ __device__ __forceinline__ void store_vec(T* __restrict__ p, uint64_t base, uint
     }
 }
 
-// The copy probe's kernel body (gymrs_copy_probe; launched through HIP from gymrs_aux.hip and, as gymrs_aql_copy_probe_*, through the
-// engine's own dispatcher): a work-item moves ITEMS 16-byte items, its loads all in flight before its first store; a workgroup a
-// contiguous chunk of 256 * ITEMS items.
-template <bool NTL, bool NTS, int ITEMS>
-__device__ __forceinline__ void copy_probe_body(const uint32_t* src, uint64_t n_read16, uint32_t* dst, uint64_t n_write16) // (src and dst may alias: in place)
-{
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const uint64_t first = (uint64_t)blockIdx.x * (kBlock * ITEMS) + threadIdx.x;
-    u4 v[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint64_t i = first + (uint64_t)j * kBlock;
-        v[j] = u4{(uint32_t)i, 1u, 2u, 3u};
-        if (i < n_read16) v[j] = NTL ? __builtin_nontemporal_load(reinterpret_cast<const u4*>(src) + i) : reinterpret_cast<const u4*>(src)[i];
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint64_t i = first + (uint64_t)j * kBlock;
-        if (i < n_write16) {
-            if (NTS)
-                __builtin_nontemporal_store(v[j], reinterpret_cast<u4*>(dst) + i);
-            else
-                reinterpret_cast<u4*>(dst)[i] = v[j];
-        } else if (v[j].x == 0xdeadbeefu && v[j].y == 0x12345678u) { // keeps the load alive when nothing is written for this item
-            dst[0] = v[j].z;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Env policies: what differs between the three env types.
 struct CartPoleT {

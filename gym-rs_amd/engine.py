@@ -376,3 +376,116 @@ class BatchedEngine:
         t, s = C.c_uint64(), C.c_uint64()
         _check(self._lib, self._lib.gymrs_get_tick(self._h, C.byref(t), C.byref(s)))
         return t.value, s.value
+
+
+class _ShardView(BatchedEngine):
+    """Block r of a ShardedEngine: the engine's views (obs / reward / done pointers, stream, env_json).  Borrowed -- the
+    sharder owns it, ``close`` is a no-op, and it must not be stepped directly while the sharder is in use."""
+
+    def __init__(self, lib, handle, kind, n_envs, offset, flags, device):
+        self._lib = lib
+        self._h = C.c_void_p(handle)
+        self.kind, self.n_envs, self.global_env_offset, self.flags, self.device = kind, n_envs, offset, flags, device
+        self.state_dim, self.obs_dim, self.action_dtype = _STATE_DIM[kind], _OBS_DIM[kind], _ACTION_DTYPE[kind]
+        self.params = None
+
+    def close(self) -> None:
+        self._h = C.c_void_p()
+
+
+class ShardedEngine:
+    """One batch of ``n_total`` lanes over several GPUs in ONE process (``gymrs_sharded_*``, include/gymrs_amd.h): contiguous
+    blocks, one engine and one native host thread per block, global lane ids -- every result is bit-identical to one
+    ``BatchedEngine`` of ``n_total`` lanes.  ``devices[r]`` is block r's device (a device may repeat)."""
+
+    def __init__(self, kind: int, n_total: int, devices: Sequence[int], *, global_env_offset: int = 0, params=None, flags: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.kind, self.n_total, self.flags = int(kind), int(n_total), int(flags)
+        self.state_dim, self.obs_dim, self.action_dtype = _STATE_DIM[self.kind], _OBS_DIM[self.kind], _ACTION_DTYPE[self.kind]
+        self.params = params if params is not None else default_params(self.kind)
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        _check(self._lib, self._lib.gymrs_sharded_create(self.kind, self.n_total, int(global_env_offset), len(devices), devs,
+                                                         C.byref(self.params), self.flags, C.byref(self._h)))
+        self.shards = []
+        for r in range(len(devices)):
+            eng, first, count, dev = C.c_void_p(), C.c_uint64(), C.c_uint64(), C.c_int()
+            _check(self._lib, self._lib.gymrs_sharded_shard(self._h, r, C.byref(eng), C.byref(first), C.byref(count), C.byref(dev)))
+            view = _ShardView(self._lib, eng.value, self.kind, count.value, int(global_env_offset) + first.value, self.flags, dev.value)
+            view.first_lane = first.value
+            self.shards.append(view)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            for s in self.shards:
+                s.close()
+            self._lib.gymrs_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ptrs(self, addresses):
+        if len(addresses) != len(self.shards):
+            raise ValueError("one device address per shard expected")
+        return (C.c_void_p * len(addresses))(*[C.c_void_p(int(a)) for a in addresses])
+
+    def reset(self, seed: Optional[int] = None, options: Optional[Sequence[float]] = None) -> int:
+        bounds = None
+        if options is not None:
+            arr = np.ascontiguousarray(options, dtype=np.float32)
+            if arr.size != 2 * self.state_dim:
+                raise ValueError(f"options needs {2 * self.state_dim} floats (lows then highs)")
+            bounds = arr.ctypes.data_as(C.POINTER(C.c_float))
+        used = C.c_uint64()
+        _check(self._lib, self._lib.gymrs_sharded_reset(self._h, 0 if seed is None else 1, 0 if seed is None else int(seed), bounds, C.byref(used)))
+        return used.value
+
+    def step(self, actions_dev: Sequence[int]) -> None:
+        """``actions_dev[r]``: device address (on block r's device) of block r's actions.  Asynchronous."""
+        _check(self._lib, self._lib.gymrs_sharded_step(self._h, self._ptrs(actions_dev)))
+
+    def step_many(self, actions_dev: Sequence[int], stride_bytes: int, n_buffers: int, n_steps: int, use_graph: bool = False) -> None:
+        _check(self._lib, self._lib.gymrs_sharded_step_many(self._h, self._ptrs(actions_dev), int(stride_bytes), int(n_buffers), int(n_steps),
+                                                            1 if use_graph else 0))
+
+    def fill_actions(self, actions_dev: Sequence[int], seed: int, t: int) -> None:
+        _check(self._lib, self._lib.gymrs_sharded_fill_actions(self._h, self._ptrs(actions_dev), int(seed), int(t)))
+
+    def sync(self) -> None:
+        _check(self._lib, self._lib.gymrs_sharded_sync(self._h))
+
+    def stats(self) -> np.ndarray:
+        """{sum_return, sum_length, n_episodes, n_steps} of the WHOLE batch (RCCL all-reduce on distinct devices, host sum otherwise)."""
+        out = (C.c_double * 4)()
+        _check(self._lib, self._lib.gymrs_sharded_stats(self._h, out))
+        return np.array(out[:], dtype=np.float64)
+
+    def stats_clear(self) -> None:
+        _check(self._lib, self._lib.gymrs_sharded_stats_clear(self._h))
+
+    @property
+    def reduce_path(self) -> str:
+        return self._lib.gymrs_sharded_reduce_path(self._h).decode()
+
+    def get_state(self, first: int = 0, count: Optional[int] = None) -> np.ndarray:
+        count = self.n_total - first if count is None else count
+        out = np.empty((self.state_dim, count), dtype=np.float32)
+        _check(self._lib, self._lib.gymrs_sharded_get_state(self._h, first, count, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get_step_result(self, first: int = 0, count: Optional[int] = None):
+        count = self.n_total - first if count is None else count
+        reward, done, trunc = np.empty(count, np.float32), np.empty(count, np.uint8), np.empty(count, np.uint8)
+        _check(self._lib, self._lib.gymrs_sharded_get_step_result(self._h, first, count, reward.ctypes.data_as(C.c_void_p),
+                                                                  done.ctypes.data_as(C.c_void_p), trunc.ctypes.data_as(C.c_void_p)))
+        return reward, done, trunc

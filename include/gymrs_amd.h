@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define GYMRS_ABI_VERSION 2
+/* 3 (round 5): + gymrs_sharded_*, gymrs_allreduce_stats_multi; - gymrs_copy_probe (a measurement tool now: tools/copy_probe) */
+#define GYMRS_ABI_VERSION 3
 
 typedef struct gymrs_engine gymrs_engine; /* opaque; owns device buffers + stream */
 
@@ -257,6 +258,50 @@ gymrs_status gymrs_comm_unique_id(uint8_t id_out[128]);
 gymrs_status gymrs_comm_init(gymrs_engine* e, int n_ranks, int rank, const uint8_t id[128]);
 gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
 
+/* ---- one batch over several GPUs, in ONE process ------------------------------------------- */
+/* The in-process form of gymrs_allreduce_stats (`gymrs_allreduce_stats(gymrs_engine** shards, int n, double out[4])`): one host
+ * thread holds every shard of a batch.  Shards on n DISTINCT devices: one RCCL communicator over exactly these engines (made on the first
+ * call, all ranks inside one ncclGroupStart/End -- a bare gymrs_comm_init per engine from one thread would wait for the other ranks for
+ * ever), then n grouped all-reduces of 32 bytes over xGMI, each on its engine's stream.  Shards sharing a device (RCCL refuses two ranks
+ * on one GPU) or n = 1: the same four doubles are summed on the host.  *used_rccl (may be NULL) says which.  Synchronising. */
+gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl);
+
+/* A batch of n_total lanes cut into n_shards contiguous blocks, one engine per block on devices[r] (NULL = devices 0 .. n_shards-1; a
+ * device may appear more than once), lane i of the batch carrying the global id global_env_offset + i whatever the cut -- so every result
+ * below is bit-identical to ONE engine of n_total lanes.  Each engine is driven by its own host thread, bound to its device, for its
+ * whole life: the calls below hand one command to every thread and return when all have ENQUEUED (the step calls stay asynchronous on
+ * each engine's stream).  One gymrs_sharded is driven by one caller thread at a time (`&mut self`, core.rs:42-50).
+ * Creation seeds every block with ONE OS-entropy seed (cartpole.rs:92,120).  Error messages name the shard and its device. */
+typedef struct gymrs_sharded gymrs_sharded;
+gymrs_status gymrs_sharded_create(gymrs_env_kind kind, uint64_t n_total, uint64_t global_env_offset, int n_shards,
+                                  const int* devices, const void* params, uint32_t flags, gymrs_sharded** out);
+gymrs_status gymrs_sharded_destroy(gymrs_sharded* h);
+gymrs_status gymrs_sharded_count(gymrs_sharded* h, int* n_shards);
+/* Block r: its engine (for the zero-copy views gymrs_obs_ptrs / gymrs_reward_ptr / ... and the stream; do not step it directly while
+ * the sharder is in use), its first lane within the batch, its lane count and its device.  Any out pointer may be NULL. */
+gymrs_status gymrs_sharded_shard(gymrs_sharded* h, int shard, gymrs_engine** engine, uint64_t* first_lane,
+                                 uint64_t* n_lanes, int* device);
+/* Env::reset for the whole batch: gymrs_reset on every block with the same seed (has_seed = 0: one fresh OS seed). */
+gymrs_status gymrs_sharded_reset(gymrs_sharded* h, int has_seed, uint64_t seed, const float* bounds_low_high,
+                                 uint64_t* seed_used);
+/* Env::step / n_steps of them: actions_dev[r] = block r's action buffer (ring) ON ITS DEVICE, laid out as for gymrs_step / gymrs_step_many. */
+gymrs_status gymrs_sharded_step(gymrs_sharded* h, const void* const* actions_dev);
+gymrs_status gymrs_sharded_step_many(gymrs_sharded* h, const void* const* actions_dev, uint64_t stride_bytes,
+                                     uint32_t n_buffers, uint32_t n_steps, int use_graph);
+gymrs_status gymrs_sharded_fill_actions(gymrs_sharded* h, void* const* actions_dev, uint64_t seed, uint64_t t);
+/* Waits for every block's stream; GYMRS_EACTION etc. as gymrs_sync (the first failing shard is reported). */
+gymrs_status gymrs_sharded_sync(gymrs_sharded* h);
+/* {sum_return, sum_length, n_episodes, n_steps} of the whole batch = gymrs_allreduce_stats_multi over the blocks. */
+gymrs_status gymrs_sharded_stats(gymrs_sharded* h, double out[4]);
+gymrs_status gymrs_sharded_stats_clear(gymrs_sharded* h);
+/* "rccl" | "host" | "none": how the last gymrs_sharded_stats summed. */
+const char* gymrs_sharded_reduce_path(gymrs_sharded* h);
+/* Host copies over lanes [first, first + count) of the BATCH, laid out exactly as gymrs_get_state / gymrs_get_step_result lay out an
+ * engine's lanes (SoA: state_dim arrays of `count` floats back to back).  Synchronising. */
+gymrs_status gymrs_sharded_get_state(gymrs_sharded* h, uint64_t first, uint64_t count, float* host_out);
+gymrs_status gymrs_sharded_get_step_result(gymrs_sharded* h, uint64_t first, uint64_t count, float* reward,
+                                           uint8_t* done, uint8_t* truncated /* each may be NULL */);
+
 /* ---- the `pub` physics fields after construction (cartpole.rs:53-82, mountain_car.rs:49-62) --- */
 /* In the reference the constants are public struct fields: `env.gravity = ...` between two step() calls touches
  * nothing else -- state, steps_beyond_terminated, the episode clock and the PRNG carry on (cartpole.rs:455-464 reads
@@ -287,19 +332,6 @@ gymrs_status gymrs_env_json(gymrs_engine* e, uint64_t lane, char* buf, uint64_t 
  * params struct.  If `state` (may be NULL, capacity 4) is given and the object has a "state", its numbers are stored
  * in field order and *state_dim (may be NULL) is set (0 when absent). */
 gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* json, void* params, double* state, int* state_dim);
-
-/* ---- measurement ("also measure an in-repo stream-copy kernel on the box") ---------- */
-/* Times `launches` back-to-back launches of a plain dwordx4 copy kernel that reads read_bytes and writes write_bytes
- * per launch (private buffers on `device`, HIP events on a private stream, after as many untimed warm-up launches) and returns the
- * mean microseconds per launch.  With read/write sizes of one step's traffic (four 16-byte items per work-item like the step kernel's
- * tiles, IN PLACE like a step: the bytes read are the first bytes written) this is the floor a step launch of that size can reach on this
- * box (it includes the fixed cost of a dependent launch); from 1.5 GiB per launch on (1 GiB + 1 GiB: two buffers, one item per work-item,
- * the shape that streams fastest) it is the HBM bandwidth a kernel can actually get.  mode = hint (0 none, 1 non-temporal loads and stores, 4 non-temporal stores only -- what leaves the
- * Infinity Cache to the bytes that are read again) | 8: one item per work-item instead of four | 2: the launches go through a chain of the library's own dispatcher (acquire-only packets, one release at the end: what gymrs_step_many's chains must be compared with; a
- * step's footprint only; GYMRS_EHIP where the dispatcher is not available) | 16: the source holds zeros.  Without 16 it holds hashed 32-bit words: on this part
- * lines of zeros move 3-14 % faster than any other content (profiles/r04_copy_content.log), and a step's arrays are not zeros. */
-gymrs_status gymrs_copy_probe(int device, uint64_t read_bytes, uint64_t write_bytes, uint32_t launches, int mode,
-                              double* us_per_launch);
 
 /* ---- utilities --------------------------------------------------------------------------------- */
 /* Random-policy actions for lane block [0, n_envs) at time t, written to actions_dev: the

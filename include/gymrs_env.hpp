@@ -187,6 +187,81 @@ private:
     int state_dim_ = 0;
 };
 
+// ---- one batch over several GPUs, in one process (gymrs_sharded_*: one engine + one native host thread per block) ---------
+// contiguous blocks of lanes, global lane ids, no exchange except the four statistics doubles (RCCL over xGMI on
+// distinct devices, a host-side sum where blocks share a device).  Every result is bit-identical to ONE VecEnv of n_total lanes.
+class ShardedVecEnv {
+public:
+    ShardedVecEnv(gymrs_env_kind kind, std::uint64_t n_total, const std::vector<int>& devices, std::uint32_t flags = 0, const void* params = nullptr,
+                  std::uint64_t global_env_offset = 0)
+        : n_(n_total), state_dim_(kind == GYMRS_CARTPOLE ? 4 : 2)
+    {
+        check(gymrs_sharded_create(kind, n_total, global_env_offset, (int)devices.size(), devices.data(), params, flags, &h_));
+    }
+    ~ShardedVecEnv() { gymrs_sharded_destroy(h_); }
+    ShardedVecEnv(const ShardedVecEnv&) = delete;
+    ShardedVecEnv& operator=(const ShardedVecEnv&) = delete;
+
+    struct Block {
+        gymrs_engine* engine; // for the zero-copy views (gymrs_obs_ptrs, gymrs_reward_ptr, ...); not to be stepped directly
+        std::uint64_t first_lane, n_lanes;
+        int device;
+    };
+    int n_blocks()
+    {
+        int k = 0;
+        check(gymrs_sharded_count(h_, &k));
+        return k;
+    }
+    Block block(int r)
+    {
+        Block b{};
+        check(gymrs_sharded_shard(h_, r, &b.engine, &b.first_lane, &b.n_lanes, &b.device));
+        return b;
+    }
+    std::uint64_t reset(std::optional<std::uint64_t> seed, const float* bounds_low_high = nullptr)
+    {
+        std::uint64_t used = 0;
+        check(gymrs_sharded_reset(h_, seed.has_value(), seed.value_or(0), bounds_low_high, &used));
+        return used;
+    }
+    // actions_dev[r]: block r's actions (ring) on ITS device
+    void step_device(const std::vector<const void*>& actions_dev) { check(gymrs_sharded_step(h_, actions_dev.data())); } // async
+    void step_many(const std::vector<const void*>& actions_dev, std::uint64_t stride_bytes, std::uint32_t n_buffers, std::uint32_t n_steps)
+    {
+        check(gymrs_sharded_step_many(h_, actions_dev.data(), stride_bytes, n_buffers, n_steps, 0));
+    }
+    void fill_actions(const std::vector<void*>& actions_dev, std::uint64_t seed, std::uint64_t t)
+    {
+        check(gymrs_sharded_fill_actions(h_, actions_dev.data(), seed, t));
+    }
+    void sync() { check(gymrs_sharded_sync(h_)); }
+    std::array<double, 4> stats() // {sum_return, sum_length, n_episodes, n_steps} of the whole batch
+    {
+        std::array<double, 4> out{};
+        check(gymrs_sharded_stats(h_, out.data()));
+        return out;
+    }
+    void stats_clear() { check(gymrs_sharded_stats_clear(h_)); }
+    std::string reduce_path() { return gymrs_sharded_reduce_path(h_); } // "rccl" | "host" | "none"
+    std::vector<float> state(std::uint64_t first, std::uint64_t count)
+    {
+        std::vector<float> out(count * state_dim_);
+        check(gymrs_sharded_get_state(h_, first, count, out.data()));
+        return out;
+    }
+    void result(std::uint64_t first, std::uint64_t count, float* reward, std::uint8_t* done, std::uint8_t* truncated)
+    {
+        check(gymrs_sharded_get_step_result(h_, first, count, reward, done, truncated));
+    }
+    std::uint64_t size() const { return n_; }
+
+private:
+    std::uint64_t n_;
+    int state_dim_;
+    gymrs_sharded* h_ = nullptr;
+};
+
 // ---- single envs with the reference's surface ------------------------------------------------------
 class CartPoleEnv {
 public:

@@ -15,6 +15,13 @@
         }                                                                          \
     } while (0)
 
+// the sharded block below needs device buffers for its action rings; this test is built with plain g++ (no HIP headers), so the two HIP entry
+// points it uses are declared by hand (hipError_t is an int-sized enum, hipSuccess = 0) and libamdhip64 is named on the link line
+extern "C" int hipSetDevice(int device);
+extern "C" int hipMalloc(void** ptr, std::size_t bytes);
+extern "C" int hipFree(void* ptr);
+extern "C" int hipGetDeviceCount(int* count);
+
 static bool close_to(double a, double b, double rel) { return std::fabs(a - b) <= rel * std::fmax(std::fabs(b), 1.0); }
 
 int main()
@@ -138,6 +145,47 @@ int main()
         REQUIRE(sa[3] == 10000.0 * 300 && sa[2] >= 10000.0 && sa[0] == -sa[1]); // 200-step limit: every lane finished once
         REQUIRE(sa == sb && sa == sc);
         REQUIRE(a.state(0, 10000) == b.state(0, 10000) && a.state(0, 10000) == c.state(0, 10000));
+    }
+    {
+        // one batch over several GPUs in ONE process (gymrs_sharded_*): 3 blocks == 1 engine, state bits and statistics.  The blocks take the box's GPUs
+        // round-robin (one GPU: they share it and the statistics are summed on the host; distinct GPUs: the grouped RCCL all-reduce)
+        int n_dev = 0;
+        REQUIRE(hipGetDeviceCount(&n_dev) == 0 && n_dev >= 1);
+        const std::uint64_t n = 3 * 4096 + 100;
+        const std::uint32_t flags = GYMRS_AUTO_RESET | GYMRS_TRACK_STATS, nbuf = 4;
+        ShardedVecEnv sh(GYMRS_CARTPOLE, n, {0, 1 % n_dev, 2 % n_dev}, flags);
+        VecEnv one(GYMRS_CARTPOLE, n, flags);
+        REQUIRE(sh.n_blocks() == 3 && sh.block(0).first_lane == 0 && sh.block(1).first_lane == sh.block(0).n_lanes);
+        REQUIRE(sh.block(0).n_lanes + sh.block(1).n_lanes + sh.block(2).n_lanes == n);
+        sh.reset(21);
+        one.reset(21);
+        const std::uint64_t pitch = 8192; // >= every block's lanes: one ring stride for all blocks
+        std::vector<void*> rings(3);
+        std::vector<const void*> crings(3);
+        for (int r = 0; r < 3; ++r) {
+            REQUIRE(hipSetDevice(sh.block(r).device) == 0 && hipMalloc(&rings[r], nbuf * pitch) == 0);
+            crings[r] = rings[r];
+        }
+        void* ring1 = nullptr;
+        REQUIRE(hipSetDevice(0) == 0 && hipMalloc(&ring1, nbuf * n) == 0);
+        for (std::uint32_t b = 0; b < nbuf; ++b) {
+            std::vector<void*> row(3);
+            for (int r = 0; r < 3; ++r) row[r] = static_cast<char*>(rings[r]) + b * pitch;
+            sh.fill_actions(row, 1, b);
+            check(gymrs_fill_actions(one.handle(), static_cast<char*>(ring1) + b * n, 1, b));
+        }
+        sh.step_device(crings); // one step with buffer 0, then 99 more through step_many
+        one.step_device(ring1);
+        sh.step_many(crings, pitch, nbuf, 99);
+        one.step_many(ring1, n, nbuf, 99);
+        sh.sync();
+        one.sync();
+        REQUIRE(sh.state(0, n) == one.state(0, n));
+        const auto a = sh.stats(), b1 = one.stats();
+        REQUIRE(a == b1 && a[3] == 100.0 * n && a[2] > 0);
+        REQUIRE(sh.reduce_path() == (n_dev >= 3 ? "rccl" : "host"));
+        for (int r = 0; r < 3; ++r) hipFree(rings[r]);
+        hipFree(ring1);
     }
     std::printf("CPP_MIRROR_OK\n");
     return 0;

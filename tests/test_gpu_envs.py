@@ -118,7 +118,7 @@ def test_cpp_trait_mirror(tmp_path):
     exe = tmp_path / "test_env_mirror"
     lib_dir = root / "gym-rs_amd"
     spawn_server.run(["g++", "-std=c++17", "-O1", f"-I{root / 'include'}", str(root / "tests" / "cpp" / "test_env_mirror.cpp"),
-                    "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
+                    "-o", str(exe), f"-L{lib_dir}", "-lgymrs_amd", "-L/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib_dir}", "-Wl,-rpath,/opt/rocm/lib"],
                    check=True, capture_output=True, text=True)
     res = spawn_server.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "CPP_MIRROR_OK" in res.stdout, res.stdout + res.stderr

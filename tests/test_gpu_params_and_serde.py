@@ -178,15 +178,26 @@ def test_action_buffers_of_any_alignment(gymrs, twin, kind):
 
 
 def test_copy_probe_reports_a_plausible_floor(gymrs):
-    lib = gymrs.load_library()
+    """tools/copy_probe (a measurement tool since ABI 3; bench.py's copy floor): HIP launches and launches of a chain of the dispatcher."""
+    import importlib.util
+    from pathlib import Path
+
+    spec = importlib.util.spec_from_file_location("copy_probe_build", Path(__file__).resolve().parent.parent / "tools" / "copy_probe" / "build.py")
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    lib = tool.load()
     us = C.c_double()
     n = 1 << 20
-    assert lib.gymrs_copy_probe(0, 17 * n, 21 * n, 300, 1, C.byref(us)) == 0
+    assert lib.gymrs_tool_copy_probe(0, 17 * n, 21 * n, 300, 1, C.byref(us)) == 0, lib.gymrs_tool_copy_probe_error()
     assert 2.0 < us.value < 12.0  # round 1 measured 5.0-5.5 us for this footprint
-    assert lib.gymrs_copy_probe(0, 1 << 29, 1 << 29, 10, 0, C.byref(us)) == 0
+    assert lib.gymrs_tool_copy_probe(0, 1 << 29, 1 << 29, 10, 0, C.byref(us)) == 0
     gbps = 2 * (1 << 29) / (us.value * 1e-6) / 1e9
     assert 3000.0 < gbps < 8000.0  # HBM3E: 8 TB/s peak, ~6.3 TB/s for a float4 copy
-    assert lib.gymrs_copy_probe(99, 16, 16, 1, 0, C.byref(us)) == 1
+    assert lib.gymrs_tool_copy_probe(99, 16, 16, 1, 0, C.byref(us)) == 1 and b"device index" in lib.gymrs_tool_copy_probe_error()
     # mode | 16: a source of zeros (what the probe copied before round 4's last evidence set); no other bit above 8 exists
-    assert lib.gymrs_copy_probe(0, 17 * n, 21 * n, 50, 16 | 1, C.byref(us)) == 0 and 2.0 < us.value < 12.0
-    assert lib.gymrs_copy_probe(0, 17 * n, 21 * n, 50, 32, C.byref(us)) == 1
+    assert lib.gymrs_tool_copy_probe(0, 17 * n, 21 * n, 50, 16 | 1, C.byref(us)) == 0 and 2.0 < us.value < 12.0
+    assert lib.gymrs_tool_copy_probe(0, 17 * n, 21 * n, 50, 32, C.byref(us)) == 1
+    # through a chain of the dispatcher (the tool's own build of it, against the tool's own code object): faster than with a release per launch
+    hip_us = tool.copy_probe(0, 17 * n, 21 * n, 300, 0)
+    chain_us = tool.copy_probe(0, 17 * n, 21 * n, 300, 2)
+    assert chain_us is None or 1.5 < chain_us < hip_us * 1.05, (chain_us, hip_us, lib.gymrs_tool_copy_probe_error())

@@ -1,0 +1,144 @@
+"""The in-process multi-GPU sharder of the C ABI (gymrs_sharded_*, gymrs_allreduce_stats_multi): a batch cut into k
+blocks -- one engine and one native host thread per block -- is bit-identical to ONE engine of the same lanes: state bits, per-step results and
+statistics.  On a one-GPU box the k blocks share cuda:0 (the statistics are then summed on the host: RCCL refuses two ranks on one device);
+with >= 2 GPUs the same test runs one block per device and the sum is the grouped RCCL all-reduce."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gymrs():
+    return importlib.import_module("gym-rs_amd")
+
+
+def devices_for(k):
+    n_dev = torch.cuda.device_count()
+    return [r % n_dev for r in range(k)]
+
+
+def rings_for(sh, nbuf, esz, dtype):
+    """One action ring per block ON THE BLOCK'S DEVICE, filled by the sharder (global lane ids -> the same actions as one engine's ring)."""
+    pitch = max(s.n_envs for s in sh.shards)  # ONE row pitch for every block: gymrs_sharded_step_many takes one stride (the last block's rows are shorter)
+    rings = [torch.zeros((nbuf, pitch), dtype=dtype, device=f"cuda:{s.device}") for s in sh.shards]
+    for b in range(nbuf):
+        sh.fill_actions([r[b].data_ptr() for r in rings], seed=1, t=b)
+    sh.sync()
+    return rings
+
+
+@pytest.mark.parametrize("k", [2, 8])
+@pytest.mark.parametrize("kind,n", [(0, 100_000), (0, 1 << 20), (1, 77_777), (2, 50_001)])
+def test_k_blocks_equal_one_engine(gymrs, kind, n, k):
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if kind == 2 else 0)
+    dtype = torch.float32 if kind == 2 else torch.uint8
+    esz = 4 if kind == 2 else 1
+    nbuf, steps = 4, 60
+    sh = gymrs.ShardedEngine(kind, n, devices_for(k), flags=flags)
+    assert len(sh.shards) == k and sum(s.n_envs for s in sh.shards) == n
+    assert [s.first_lane for s in sh.shards] == list(np.cumsum([0] + [s.n_envs for s in sh.shards[:-1]]))
+    assert all(s.n_envs % 1024 == 0 for s in sh.shards[:-1]) or n < 1024 * k  # ragged tails are kept to the last block
+    one = gymrs.BatchedEngine(kind, n, flags=flags, device=0)
+    sh.reset(seed=11)
+    one.reset(seed=11)
+    assert np.array_equal(sh.get_state().view(np.uint32), one.get_state().view(np.uint32))
+    rings = rings_for(sh, nbuf, esz, dtype)
+    ring1 = torch.empty((nbuf, n), dtype=dtype, device="cuda:0")
+    for b in range(nbuf):
+        one.fill_actions(ring1[b].data_ptr(), seed=1, t=b)
+    one.sync()
+    cat = torch.cat([r[:, :s.n_envs].to("cuda:0") for r, s in zip(rings, sh.shards)], dim=1)
+    assert torch.equal(cat, ring1)  # the blocks' rings ARE the unsharded ring: global lane ids in the Philox counters
+    # single steps (gymrs_sharded_step: one command per block per step), then one gymrs_sharded_step_many
+    for t in range(7):
+        sh.step([r[t % nbuf].data_ptr() for r in rings])
+        one.step(ring1[t % nbuf].data_ptr())
+    sh.step_many([r.data_ptr() for r in rings], rings[0].stride(0) * esz, nbuf, steps)
+    one.step_many(ring1.data_ptr(), n * esz, nbuf, steps)
+    sh.sync()
+    one.sync()
+    assert np.array_equal(sh.get_state().view(np.uint32), one.get_state().view(np.uint32))
+    for a, b in zip(sh.get_step_result(), one.get_step_result()):
+        assert np.array_equal(a, b)
+    got, want = sh.stats(), one.stats()
+    assert np.array_equal(got[1:], want[1:]) and (got[0] == want[0] if kind != 2 else got[0] == pytest.approx(want[0], rel=1e-12))
+    assert got[3] == (7 + steps) * n
+    assert sh.reduce_path == ("rccl" if len(set(devices_for(k))) == k and k > 1 else "host")
+    # a window of lanes that straddles block boundaries
+    lo, cnt = sh.shards[1].first_lane - 5, 11
+    assert np.array_equal(sh.get_state(lo, cnt).view(np.uint32), one.get_state(lo, cnt).view(np.uint32))
+    sh.stats_clear()
+    assert sh.stats()[3] == 0
+    sh.close()
+    one.close()
+
+
+def test_blocks_of_equal_size_step_many_and_invalid_actions(gymrs):
+    """Equal blocks share one ring stride: a long gymrs_sharded_step_many (chains where the dispatcher is available) stays bit-identical to one engine;
+    an invalid action in ONE block is reported by gymrs_sharded_sync with the shard and its device in the message (the reference panics: cartpole.rs:402-406)."""
+    k, n, nbuf, steps = 4, 4 * 65536, 8, 300
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    sh = gymrs.ShardedEngine(gymrs.CARTPOLE, n, devices_for(k), flags=flags)
+    one = gymrs.BatchedEngine(gymrs.CARTPOLE, n, flags=flags, device=0)
+    assert {s.n_envs for s in sh.shards} == {65536}
+    sh.reset(seed=3)
+    one.reset(seed=3)
+    rings = rings_for(sh, nbuf, 1, torch.uint8)
+    ring1 = torch.cat([r.to("cuda:0") for r in rings], dim=1).contiguous()
+    sh.step_many([r.data_ptr() for r in rings], 65536, nbuf, steps)
+    one.step_many(ring1.data_ptr(), n, nbuf, steps)
+    sh.sync()
+    one.sync()
+    assert np.array_equal(sh.get_state().view(np.uint32), one.get_state().view(np.uint32))
+    assert np.array_equal(sh.stats(), one.stats()) and sh.stats()[2] > 0
+    rings[2][0, 17] = 9  # not in Discrete(2)
+    sh.step([r[0].data_ptr() for r in rings])
+    with pytest.raises(gymrs.InvalidActionError) as exc:
+        sh.sync()
+    assert "shard 2 (device" in str(exc.value)
+    sh.close()
+    one.close()
+
+
+def test_allreduce_stats_multi_over_caller_made_engines(gymrs):
+    """SURVEY 8b's form: the caller made the engines itself (global offsets by hand) and hands the array over."""
+    lib = gymrs.load_library()
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    n_dev = torch.cuda.device_count()
+    engs = [gymrs.BatchedEngine(gymrs.MOUNTAIN_CAR, 5000, global_env_offset=5000 * r, device=r % n_dev, flags=flags) for r in range(3)]
+    acts = []
+    for e in engs:
+        e.reset(seed=5)
+        a = torch.empty(5000, dtype=torch.uint8, device=f"cuda:{e.device if hasattr(e, 'device') else 0}")
+        acts.append(a)
+    for t in range(250):
+        for e, a in zip(engs, acts):
+            e.fill_actions(a.data_ptr(), seed=1, t=t)
+            e.step(a.data_ptr())
+    handles = (C.c_void_p * 3)(*[e._h for e in engs])
+    out, used = (C.c_double * 4)(), C.c_int(-1)
+    assert lib.gymrs_allreduce_stats_multi(handles, 3, out, C.byref(used)) == 0, lib.gymrs_last_error()
+    want = sum(e.stats() for e in engs)
+    assert list(out) == list(want) and out[3] == 3 * 5000 * 250 and used.value == (1 if n_dev >= 3 else 0)
+    # the same engine twice, a NULL shard, n = 0: refused
+    twice = (C.c_void_p * 2)(engs[0]._h, engs[0]._h)
+    assert lib.gymrs_allreduce_stats_multi(twice, 2, out, None) == 1 and b"twice" in lib.gymrs_last_error()
+    assert lib.gymrs_allreduce_stats_multi(handles, 0, out, None) == 1
+    for e in engs:
+        e.close()
+
+
+def test_sharder_refuses_what_it_cannot_do(gymrs):
+    lib = gymrs.load_library()
+    h = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.gymrs_sharded_create(0, 1, 0, 2, devs, None, 0, C.byref(h)) == 1 and b"fewer lanes than shards" in lib.gymrs_last_error()
+    assert lib.gymrs_sharded_create(0, 100, 0, 0, devs, None, 0, C.byref(h)) == 1
+    bad = (C.c_int * 2)(0, 99)
+    assert lib.gymrs_sharded_create(0, 100, 0, 2, bad, None, 0, C.byref(h)) == 1 and b"shard 1 (device 99)" in lib.gymrs_last_error() and not h.value
+    assert lib.gymrs_sharded_destroy(None) == 0 and lib.gymrs_sharded_reduce_path(None) == b"none"

@@ -144,7 +144,7 @@ def main():
             eng.sync()
             rec["graph_us"] = e0.elapsed_time(e1) * 1e3 / graph_steps
             us = C.c_double()
-            if lib.gymrs_copy_probe(0, n * 17 // 16 * 16, n * 21 // 16 * 16, 200, 1, C.byref(us)) == 0:
+            if lib.gymrs_tool_copy_probe(0, n * 17 // 16 * 16, n * 21 // 16 * 16, 200, 1, C.byref(us)) == 0:
                 rec["copy_same_footprint_us"] = us.value
             if probe.alu_probe(4000, C.byref(us)) == 0:
                 rec["alu_kernel_us"] = us.value

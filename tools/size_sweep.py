@@ -17,6 +17,11 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 gymrs = importlib.import_module("gym-rs_amd")
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location("gymrs_copy_probe_tool", ROOT / "tools" / "copy_probe" / "build.py")
+probe = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(probe)  # the copy yardstick: a tool of its own since round 5 (tools/copy_probe)
 BYTES = {0: (17, 21), 1: (9, 13), 2: (12, 25)}
 
 
@@ -61,9 +66,8 @@ def main():
         out = []
         chained = 2 if os.environ.get("GYMRS_AQL", "1") != "0" else 0  # the copy is submitted the way the steps are (chains unless GYMRS_AQL=0)
         for hint in (0, 1, 4):  # none | loads and stores | stores only
-            us = C.c_double()
-            stt = lib.gymrs_copy_probe(0, n * rd // 16 * 16, n * (wr - elided) // 16 * 16, max(20, steps // 4), hint | chained, C.byref(us))
-            out.append(us.value if stt == 0 else float("nan"))
+            us = probe.copy_probe(0, n * rd // 16 * 16, n * (wr - elided) // 16 * 16, max(20, steps // 4), hint | chained)
+            out.append(us if us is not None else float("nan"))
         gbps = n * (rd + wr) / (best * 1e-6) / 1e9
         frac = "" if chained else f" ({gbps / 8000:.3f} of 8 TB/s)"  # (a chain's state is read out of the L2s at the small sizes: no HBM fraction)
         print(f"2^{lg:2d} lanes: step {best:9.2f} us  {gbps:7.1f} GB/s algorithmic{frac}   in-place copy, {'chain' if chained else 'HIP launches'}: "
