@@ -252,6 +252,9 @@ def parse_args(argv=None):
     ap.add_argument("--pmc-traffic", action="store_true",
                     help="N=1: also run two short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE) and "
                          "report the traffic they measure (and refresh profiles/pmc_traffic.json)")
+    ap.add_argument("--in-process", action="store_true",
+                    help="ONE process drives all N GPUs through the C ABI's native sharder (gymrs_sharded_*: one engine + one host thread per device, grouped RCCL "
+                         "all-reduce) instead of one process per GPU; the line's `sharder` says which form ran.  With --oversubscribe the N blocks share the box's GPUs")
     ap.add_argument("--full-out", default="", help="where the complete record goes (default: bench_full.json next to this script); the printed line names it")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="TEST ONLY: ranks share GPUs (rank r -> device r %% device_count) and meet over gloo, so that the "
@@ -665,6 +668,7 @@ def run_rank(args, info, backend, make_collective=None):
             },
             "ranks": per_rank,
             "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},
+            "sharder": "process-per-gpu" if info.world > 1 else "single engine",
         }
         if per_step:
             out["roofline"] = hd["roofline"]
@@ -760,6 +764,10 @@ def run_rank(args, info, backend, make_collective=None):
                 out["mode"] = "hip_graph_replays"
                 launch_us = kernel_ms * 1e3 / steps_timed
                 out["roofline"] = roofline_of("per_step_visible", n, bytes_per_step, launch_us, None, "graph replays: no committed traffic figure", extras().get("last_launch"), sha)
+    if info.is_root and info.world == 1 and backend.name == "hip" and per_step and HEADLINE_PATH in (out.get("paths") or {}) and hasattr(eng, "env_json"):
+        q_us = measure_visible_through_queue(backend, eng, stream, act_ptr, act_stride, nbuf, args.steps * max(1, passes // 5))
+        if q_us:
+            out["paths"][HEADLINE_PATH]["roofline"]["queue_launch_us"] = q_us  # (the same dict object as out["roofline"] when the headline is this shape)
     eng.close()
     if (info.is_root and info.world == 1 and backend.name == "hip" and per_step and args.path == "both" and not args.no_configs and args.env == "cartpole"
             and not args.n_envs and not args.vec and not args.nt):
@@ -775,6 +783,34 @@ def run_rank(args, info, backend, make_collective=None):
     coll.close()
     args.hard_exit = run.abandoned  # a helper thread may still sit inside a native call that never returns
     return out
+
+
+def measure_visible_through_queue(backend, eng, stream, act_ptr, act_stride, nbuf, steps_per_call, repetitions=5):
+    """The per-step-visible shape submitted through the ENGINE'S OWN QUEUE instead of through HIP (GYMRS_AQL=2, VERDICT r4 "next" #4): every packet carries HIP's
+    header (agent-scope acquire + release) and the launch uses HIP launches' memory hints, so every step's arrays are written back when its launch ends -- at
+    0.3-0.5 us of host time per launch instead of 2.5-4.  Reported beside the HIP-launched figure (`queue_launch_us`), never instead of it: the faster of the two
+    differs by env and size (profiles/r05_visible_through_queue.log).  None where the dispatcher is not available."""
+    before = os.environ.get("GYMRS_AQL")
+    os.environ["GYMRS_AQL"] = "2"
+    try:
+        launched = json.loads(eng.env_json(0))["gymrs"].get("aql_launches", 0)
+        eng.step_many(act_ptr, act_stride, nbuf, steps_per_call)  # untimed: caches and clocks are this submission's own
+        eng.sync()
+        us = []
+        for _ in range(repetitions):
+            m0 = backend.mark(stream)
+            eng.step_many(act_ptr, act_stride, nbuf, steps_per_call)
+            m1 = backend.mark(stream)
+            eng.sync()
+            us.append(backend.elapsed_ms(m0, m1) * 1e3 / steps_per_call)
+        if json.loads(eng.env_json(0))["gymrs"].get("aql_launches", 0) <= launched:
+            return None
+        return statistics.median(us)
+    finally:
+        if before is None:
+            os.environ.pop("GYMRS_AQL", None)
+        else:
+            os.environ["GYMRS_AQL"] = before
 
 
 def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=False, repetitions=5):
@@ -828,6 +864,9 @@ def measure_config(backend, gymrs, config_name, env_name, n, nbuf, no_probe=Fals
                 roof["same_footprint_copy_us"] = min(cands)
                 roof["frac_of_same_footprint_copy"] = min(cands) / launch_us
         rec["paths"][path] = prec
+    q_us = measure_visible_through_queue(backend, eng, stream, act_ptr, act_stride, nbuf, k * max(1, int(math.ceil(20.0 / max(per_pass, 1e-3)))))
+    if q_us:
+        rec["paths"][HEADLINE_PATH]["roofline"]["queue_launch_us"] = q_us
     stats = eng.stats()
     eng.close()
     del _ring
@@ -848,7 +887,7 @@ def _sig(x, digits=6):
 
 
 def _roof_brief(r, keys=("bound", "achieved", "peak", "unit", "frac", "frac_moved", "frac_counted", "traffic", "kernel", "bytes_per_launch", "launch_us",
-                         "hbm_bound", "traffic_from", "frac_of_same_footprint_copy")):
+                         "hbm_bound", "traffic_from", "frac_of_same_footprint_copy", "queue_launch_us")):
     return {k: (r[k][:120] if isinstance(r[k], str) else _sig(r[k])) for k in keys if k in r}
 
 
@@ -869,14 +908,14 @@ def compact_line(out: dict, full_path) -> str:
                           "event_us_per_step": {k: _sig(v) for k, v in (t.get("event_us_per_step") or {}).items()}}
     if "roofline" in out:
         line["roofline"] = _roof_brief(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_moved", "frac_counted", "traffic", "kernel", "bytes_per_launch",
-                                                         "launch_us", "hbm_bound", "traffic_from", "frac_of_same_footprint_copy", "valu_instr_per_wave_step", "ns_per_lane_step"))
+                                                         "launch_us", "hbm_bound", "traffic_from", "frac_of_same_footprint_copy", "queue_launch_us", "valu_instr_per_wave_step", "ns_per_lane_step"))
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
                                 "sample": cb.get("sample_brief") or cb.get("sample", "")[:160]}
         if cb.get("multi_thread"):
             line["cpu_baseline"]["multi_thread"] = {"value": _sig(cb["multi_thread"]["value"]), "cores": cb["multi_thread"]["cores"]}
-    small = ("bound", "frac", "frac_moved", "frac_counted")
+    small = ("bound", "frac", "frac_moved", "frac_counted", "queue_launch_us")
     for name, p in (out.get("paths") or {}).items():
         if name != c.get("call_shape"):
             line.setdefault("paths", {})[name] = {"value": _sig(p["value"]), "launch_us": _sig(p["launch_us"]), **_roof_brief(p.get("roofline", {}), small)}
@@ -914,11 +953,133 @@ def write_full_record(out: dict, where) -> "Path | None":
     return None
 
 
+def run_in_process(args):
+    """`--in-process`: the whole job in ONE process through the C ABI's native sharder (include/gymrs_amd.h gymrs_sharded_*): a batch
+    of N x lanes_per_gpu lanes cut into N contiguous blocks, one engine and one native host thread per device, the statistics summed by ONE grouped RCCL
+    all-reduce after the clock (host-side sum where blocks share a device).  Same workload, same timing rules as the process-per-GPU form: W warm-up steps, a
+    settle phase, R repetitions of one gymrs_sharded_step_many(P * K) each between synchronises (wall clock) and between HIP events on EVERY block's stream
+    (the repetition's event time = the max over blocks), the median over repetitions."""
+    import torch
+
+    gymrs = importlib.import_module("gym-rs_amd")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the stepper has no CPU fallback")
+    n_dev = torch.cuda.device_count()
+    if args.gpus > n_dev and not args.oversubscribe:
+        raise SystemExit(f"bench.py --in-process: --gpus {args.gpus} but only {n_dev} GPUs are visible (one block per GPU; --oversubscribe shares them: TEST only)")
+    devices = [r % n_dev for r in range(args.gpus)]
+    kind, n_default, bytes_read, bytes_written, workload = ENVS[args.env]
+    n = args.n_envs or n_default
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | (gymrs.TIME_LIMIT if args.env == "pendulum" else 0)
+    sh = gymrs.ShardedEngine(kind, n * args.gpus, devices, flags=flags)
+    is_float = args.env == "pendulum"
+    esz = 4 if is_float else 1
+    nbuf = max(1, args.action_buffers)
+    pitch = max(s.n_envs for s in sh.shards)
+    rings = [torch.empty((nbuf, pitch), dtype=torch.float32 if is_float else torch.uint8, device=f"cuda:{s.device}") for s in sh.shards]
+    for b in range(nbuf):
+        sh.fill_actions([r[b].data_ptr() for r in rings], seed=1, t=b)
+    sh.reset(seed=0)
+    ptrs = [r.data_ptr() for r in rings]
+    streams = [torch.cuda.ExternalStream(s.stream, device=torch.device("cuda", s.device)) for s in sh.shards]
+
+    def run_steps(k):
+        sh.step_many(ptrs, pitch * esz, nbuf, k)
+
+    def timed(k):
+        sh.sync()
+        marks = []
+        for st, s in zip(streams, sh.shards):
+            with torch.cuda.device(s.device):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(st)
+                marks.append(ev)
+        t0 = time.perf_counter()
+        run_steps(k)
+        ends = []
+        for st, s in zip(streams, sh.shards):
+            with torch.cuda.device(s.device):
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(st)
+                ends.append(ev)
+        sh.sync()
+        wall = time.perf_counter() - t0
+        return wall, [a.elapsed_time(b) for a, b in zip(marks, ends)]
+
+    with submission(HEADLINE_PATH if args.path in ("both", HEADLINE_PATH) else "chain"):
+        head = HEADLINE_PATH if args.path in ("both", HEADLINE_PATH) else "chain"
+        run_steps(args.warmup)
+        sh.sync()
+        first, _ = timed(args.steps)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < SETTLE_SECONDS:
+            run_steps(max(args.steps, int(2e-3 / max(first / args.steps, 1e-9))))
+            sh.sync()
+        per_pass, _ = timed(args.steps * 8)
+        passes = int(os.environ.get("GYMRS_BENCH_PASSES") or choose_passes(per_pass / 8, args.min_repetition_ms * 1e-3))
+        sh.stats_clear()
+        reps = max(1, args.repetitions)
+        walls, events = [], []
+        for _ in range(reps + 1):  # (one uncounted lead-in repetition, as in the process-per-GPU form)
+            w, ev = timed(args.steps * passes)
+            walls.append(w)
+            events.append(ev)
+        walls, events = walls[1:], events[1:]
+    total = sh.stats()
+    reduce_path = sh.reduce_path
+    steps_timed = args.steps * passes
+    assert total[3] == float(n * args.gpus) * steps_timed * (reps + 1), (total, steps_timed)
+    wall = statistics.median(walls)
+    per_block_us = [statistics.median(e[r] for e in events) * 1e3 / steps_timed for r in range(args.gpus)]
+    launch_us = statistics.median(max(e) for e in events) * 1e3 / steps_timed
+    sha = kernel_source_sha16()
+    ex = json.loads(sh.shards[0].env_json(0))["gymrs"]
+    config_name = "cartpole_2p20" if (args.env == "cartpole" and n == n_default and args.gpus == 1) else None
+    trec, tnote = load_free_running_traffic(config_name, head, sha) if config_name else (None, "no committed traffic figure for this shape")
+    roof = roofline_of(head, n, bytes_read + bytes_written, per_block_us[0], trec, tnote, ex.get("last_launch"), sha, moved_bytes(args.env, ex))
+    ev_us = sorted(max(e) * 1e3 / steps_timed for e in events)
+    out = {
+        "metric": "env-steps/sec (whole node), CartPole-v1 @ 2^20 envs per MI355X" if args.env == "cartpole" else f"env-steps/sec (whole node), {args.env}",
+        "value": n * args.gpus * steps_timed / wall, "unit": "env-steps/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall * 1e3 / steps_timed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "env": args.env, "lanes_per_gpu": n, "total_lanes": n * args.gpus, "call_shape": head, "action_buffers": nbuf,
+                   "parallelism": f"lane-sharded x{args.gpus} in one process, no data-path collective; 1 all-reduce of 4 f64 per run, after the clock",
+                   "stats_allreduce": {"rccl": "gymrs_sharded_stats: grouped RCCL all-reduce (one communicator over the blocks' engines)",
+                                       "host": "gymrs_sharded_stats: host-side sum (blocks share a device, or one block)"}.get(reduce_path, reduce_path),
+                   "devices": devices},
+        "timing": {"repetitions": reps, "passes_per_repetition": passes, "steps_per_repetition": steps_timed, "wall_ms_per_repetition": [w * 1e3 for w in walls],
+                   "event_us_per_step": {"min": ev_us[0], "median": statistics.median(ev_us), "max": ev_us[-1], "spread": (ev_us[-1] - ev_us[0]) / statistics.median(ev_us)},
+                   "statistic": "median over repetitions of the max over blocks"},
+        "roofline": roof,
+        "ranks": [{"rank": r, "device": s.device, "global_env_offset": s.global_env_offset, "launch_us": per_block_us[r]} for r, s in enumerate(sh.shards)],
+        "ranks_agree": True,
+        "episodes": {"sum_return": float(total[0]), "sum_length": float(total[1]), "n_episodes": float(total[2])},
+        "sharder": "in-process",
+        "sharder_note": "gymrs_sharded_* (include/gymrs_amd.h): one engine + one native host thread per block; bit-identical to one engine of the same lanes "
+                        "(tests/test_gpu_sharded_native.py)",
+    }
+    if args.oversubscribe and args.gpus > n_dev:
+        out["oversubscribed"] = "TEST RUN: blocks share GPUs; value is not a benchmark result"
+    del launch_us
+    if args.cpu_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(kind, min(args.cpu_seconds, 2.0) if args.gpus > 1 else args.cpu_seconds)
+    sh.close()
+    return out
+
+
 def main(argv=None) -> int:
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     gymrs = importlib.import_module("gym-rs_amd")
     sharded = gymrs.sharded
+    if args.in_process:
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)  # (RCCL's banner and friends: to stderr, as in the process-per-GPU form)
+        out = run_in_process(args)
+        os.write(json_fd, (compact_line(out, write_full_record(out, args.full_out)) + "\n").encode())
+        os.close(json_fd)
+        return 0
     if sharded.needs_spawn(args.gpus, force=os.environ.get("GYMRS_BENCH_FORCE_SPAWN") == "1"):
         # plain `python bench.py --gpus N`: become the launcher of N ranks, one process per GPU
         return sharded.spawn_ranks(str(Path(__file__).resolve()), argv, args.gpus)

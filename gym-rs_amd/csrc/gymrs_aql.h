@@ -44,7 +44,8 @@ class AqlChain;
 // device memory, no stream memory operations, a failed self-check, GYMRS_AQL=0, ...
 AqlChain* aql_create(int hip_device, std::string* why);
 // parks the object (queue, rings, flags) for the next aql_create on the device: hardware queues are created once, not per engine
-void aql_destroy(AqlChain* c);
+// discard: an error path (a failed hand-over, a tripped XCD check, a stream that could not be waited for) -- the queue is given back, not parked.
+void aql_destroy(AqlChain* c, bool discard = false);
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out);
 
 // Largest kernel-argument block one dispatch may carry.
@@ -54,8 +55,9 @@ constexpr size_t kAqlKernargSlot = 512;
 // stays usable only for aql_destroy (the engine then falls back to HIP launches for good).
 bool aql_begin(AqlChain* c, hipStream_t stream, std::string* err);
 // grid_workitems = workgroups * workgroup_size.  Kernel arguments are copied.
+// release: the packet also carries an agent-scope RELEASE (HIP's own header) instead of the chain's acquire-only one.
 bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes,
-                  std::string* err);
+                  std::string* err, bool release = false);
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* err);
 // != 0 once a chain's first packet gave up waiting for the stream (checked by gymrs_sync); cleared by the call
 uint32_t aql_take_error(AqlChain* c);

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void aql_hip_wait_flag(const uint32_t* flag, ui
 constexpr uint32_t kQueuePackets = 4096;
 constexpr uint32_t kKernargSlots = 8 * kQueuePackets; // a slot is rewritten only after kQueuePackets later packets were CONSUMED
 constexpr uint32_t kFlushEvery = 64;
+constexpr size_t kHostErrWords = 16; // the mapped host block a chain reports through (64 bytes; [0] is the word in use)
 constexpr uint32_t kCalibItems = 1u << 18; // 16-byte items of aql_calibrate's probe chains (4 MB)
 
 const char* hsa_err(hsa_status_t s)
@@ -196,6 +197,7 @@ public:
     uint32_t calibrated_epoch = 0;
     bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
+    hsa_signal_t pace{}; // (developer experiment GYMRS_AQL_EXP=1: a completion signal on every releasing packet, as the HIP runtime attaches one)
     // 8 entries (one cache line each) the first step launch of every chain records {chain number, XCC} of its workgroups 0 .. 7 in and the
     // later launches of that chain compare against (StepArgs::xcc_table)
     uint32_t* xcc_table = nullptr;
@@ -329,7 +331,11 @@ bool load_code(DeviceCtx* c, std::string* why)
 bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why, std::atomic<int>* status = nullptr)
 {
     static const uint32_t queue_packets = [] { const char* v = std::getenv("GYMRS_AQL_QUEUE"); return v ? (uint32_t)std::strtoul(v, nullptr, 0) : kQueuePackets; }();
-    HSA_OK(hsa_queue_create(c->gpu, queue_packets, HSA_QUEUE_TYPE_SINGLE, queue_error, status ? status : &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
+    // (developer experiment GYMRS_AQL_EXP: 2 a MULTI-producer queue, 4 high priority, 8 profiling enabled on the queue -- what the HIP runtime's own queues have)
+    static const int exp_bits = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return v ? std::atoi(v) : 0; }();
+    HSA_OK(hsa_queue_create(c->gpu, queue_packets, (exp_bits & 2) ? HSA_QUEUE_TYPE_MULTI : HSA_QUEUE_TYPE_SINGLE, queue_error, status ? status : &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
+    if (exp_bits & 4) (void)hsa_amd_queue_set_priority(ch->q, HSA_AMD_QUEUE_PRIORITY_HIGH);
+    if (exp_bits & 8) (void)hsa_amd_profiling_set_profiler_enabled(ch->q, 1);
     void* ka = nullptr;
     HSA_OK(hsa_amd_memory_pool_allocate(c->gpu_pool, (size_t)kKernargSlots * kAqlKernargSlot, 0, &ka), "kernel-argument ring");
     ch->kernarg = static_cast<char*>(ka);
@@ -532,7 +538,7 @@ AqlChain* aql_create(int hip_device, std::string* why)
             ch->staged.clear();
             ch->calibrated = false; // the next engine's stream is another one
             ch->sync_mode = ch->forced_sync;
-            if (ch->host_err) ch->host_err[0] = 0;
+            if (ch->host_err) std::memset(ch->host_err, 0, kHostErrWords * sizeof(uint32_t)); // every word, not only [0]
             return ch;
         }
     }
@@ -561,10 +567,10 @@ AqlChain* aql_create(int hip_device, std::string* why)
     }
     if (ok) {
         void* p = nullptr;
-        ok = hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess;
+        ok = hipHostMalloc(&p, kHostErrWords * sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
         ch->host_err = static_cast<uint32_t*>(p);
         if (ok) {
-            ch->host_err[0] = 0;
+            std::memset(ch->host_err, 0, kHostErrWords * sizeof(uint32_t));
             ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&ch->host_err_dev), p, 0) == hipSuccess;
         }
         if (!ok) *why = "hipHostMalloc (error word) failed";
@@ -629,6 +635,7 @@ static void aql_discard(AqlChain* c)
     if (c->ctx) c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
+    if (c->pace.handle) hsa_signal_destroy(c->pace);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
     if (c->xcc_table) (void)hipFree(c->xcc_table);
     if (c->in_flag) (void)hipFree(c->in_flag);
@@ -640,9 +647,13 @@ static void aql_discard(AqlChain* c)
 
 // The engine is done with its chain object (its stream is idle: every chain ended with a wait on it).  A complete, healthy object is
 // parked for the next engine of the device; anything else is discarded.
-void aql_destroy(AqlChain* c)
+void aql_destroy(AqlChain* c, bool discard)
 {
     if (!c) return;
+    if (discard) {
+        aql_discard(c);
+        return;
+    }
     const bool complete = c->ctx && c->q && c->kernarg && c->xcc_table && c->in_flag && c->out_flag && c->host_err && c->done.handle;
     if (!complete || c->in_chain || c->queue_status.load() != 0) {
         aql_discard(c);
@@ -693,14 +704,23 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
     return true;
 }
 
-bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes, std::string* why)
+bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes, std::string* why,
+                  bool release)
 {
     // barrier bit: after the previous packet has completed.  Agent-scope ACQUIRE (L1 and scalar caches start clean: free,
     // measured), NO release: the lines this launch leaves dirty in an XCD's L2 are read by the next launch on that same XCD.
     // (GYMRS_AQL_FENCES="<acquire><release>", digits 0 none / 1 agent / 2 system: developer knob for A/B runs)
     static const int acq = [] { const char* v = std::getenv("GYMRS_AQL_FENCES"); return v && v[0] >= '0' && v[0] <= '2' ? v[0] - '0' : (int)HSA_FENCE_SCOPE_AGENT; }();
     static const int rel = [] { const char* v = std::getenv("GYMRS_AQL_FENCES"); return v && v[0] && v[1] >= '0' && v[1] <= '2' ? v[1] - '0' : (int)HSA_FENCE_SCOPE_NONE; }();
-    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, rel, hsa_signal_t{0}, why);
+    // release = true: HIP's own header on this packet (agent-scope acquire AND release): what the launch wrote is written back when it ends -- the
+    // per-step-visible shape submitted through this queue (gymrs_engine.hip, GYMRS_AQL=2)
+    static const int exp_bits = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return v ? std::atoi(v) : 0; }();
+    hsa_signal_t sig{0};
+    if (release && (exp_bits & 1)) {
+        if (!c->pace.handle && hsa_signal_create(1ll << 40, 0, nullptr, &c->pace) != HSA_STATUS_SUCCESS) c->pace.handle = 0;
+        sig = c->pace;
+    }
+    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, release ? (int)HSA_FENCE_SCOPE_AGENT : rel, sig, why);
 }
 
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)

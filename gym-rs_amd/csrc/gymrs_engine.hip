@@ -467,20 +467,25 @@ gymrs_status gymrs_observation_space(gymrs_env_kind kind, const void* params, do
 }
 
 // GYMRS_AQL=0: HIP launches only (looked up per call: tests flip it)
-static bool aql_enabled_by_env()
+// GYMRS_AQL (looked up per call): "0" = HIP launches only; "2" = gymrs_step_many's launches go through the engine's queue with HIP's OWN packet header
+// (agent-scope acquire + RELEASE on every launch) and the memory hints HIP launches use -- the per-step-visible shape (every step's arrays are
+// written back when its launch ends) without the HIP runtime's 2.5-4 us of host time per launch; anything else = chains (release at the end only).
+static int aql_mode_by_env()
 {
     const char* v = std::getenv("GYMRS_AQL");
-    return !(v && v[0] == '0');
+    return (v && v[0] == '0') ? 0 : ((v && v[0] == '2') ? 2 : 1);
 }
+static bool aql_enabled_by_env() { return aql_mode_by_env() != 0; }
 
 // ---------------------------------------------------------------------------------------------
 gymrs_status gymrs_engine_destroy(gymrs_engine* e)
 {
     if (!e) return GYMRS_OK;
     (void)hipSetDevice(e->device);
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    const bool idle = !e->stream || hipStreamSynchronize(e->stream) == hipSuccess;
     comm_destroy(e);
-    aql_destroy(e->aql); // (the stream is idle: every chain ended with a wait on it)
+    // parked for the next engine of the device only when the stream really is idle (every chain ended with a wait on it) and no chain is open
+    aql_destroy(e->aql, /*discard=*/!idle || e->chain_open || (e->err_seen && e->err_seen[1] != 0));
     if (e->device >= 0 && e->device < kMaxDevices) { // a later engine at the same address must not pass for this one
         const gymrs_engine* self = e;
         g_last_stepper[e->device].compare_exchange_strong(self, nullptr, std::memory_order_relaxed);
@@ -1164,7 +1169,7 @@ static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
 
 extern "C++" {
 template <class Consts>
-static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const StepArgs& a, const Consts& c, std::string* err)
+static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const StepArgs& a, const Consts& c, std::string* err, bool release)
 {
     StepKernArgs<Consts> ka;
     std::memset(&ka, 0, sizeof(ka));
@@ -1183,7 +1188,7 @@ static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const Ste
         *err = "kernel-argument segment of the chain kernel is " + std::to_string(k.kernarg_bytes) + " bytes, the dispatcher fills " + std::to_string(sizeof(ka));
         return false;
     }
-    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads * kStepTiles) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err);
+    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads * kStepTiles) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err, release);
 }
 } // extern "C++"
 
@@ -1199,22 +1204,22 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
     }
     // (test hook, tests/test_gpu_aql_chain.py: a table nobody's XCC matches -- and no recording launch -- stands in for a deal that changed
     // in mid-chain; the memset sits on the stream ahead of the hand-over into the chain)
-    const char* dev_no = std::getenv("GYMRS_DEV_NO_XCC_CHECK"); // (developer knob, A/B runs only: what the check costs)
-    const bool no_xcc_check = dev_no && dev_no[0] == '1';
-    const char* wrong = std::getenv("GYMRS_AQL_TEST_WRONG_XCC");
-    const bool poisoned = wrong && wrong[0] == '1';
+    // (test / developer hooks, set through gymrs_dev_set_hooks -- not in the header, not read from the environment on the stepping path)
+    const bool no_xcc_check = (e->dev_hooks & 2u) != 0; // A/B runs only: what the check costs
+    const bool poisoned = (e->dev_hooks & 1u) != 0;     // tests/test_gpu_aql_chain.py: a table nobody's XCC matches
     if (poisoned) HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(aql_xcc_table(e->aql)), 0x11, 8 * kXccTableStride, e->stream));
     if (!aql_begin(e->aql, e->stream, &err)) { // nothing dispatched, no host state touched: this engine goes back to HIP launches for good
         e->aql_why = "aql_begin: " + err;
-        aql_destroy(e->aql);
+        aql_destroy(e->aql, /*discard=*/true); // (an object whose hand-over failed is not parked for the next engine)
         e->aql = nullptr;
         return GYMRS_OK;
     }
     e->chain_open = e->chain_first = true;
     *taken = true;
+    // GYMRS_AQL=2: every launch RELEASES (HIP's header) and uses HIP launches' hints: nothing rests on lines staying in an XCD's L2, so no XCD check either
+    const bool visible = aql_mode_by_env() == 2;
     int threads = step_threads_of(e->kind, e->n, e->vec);
-    if (const char* v = std::getenv("GYMRS_DEV_THREADS")) // (developer knob: 256 work-items per workgroup for CartPole chains)
-        if (e->kind == GYMRS_CARTPOLE && std::atoi(v) == kBlock) threads = kBlock;
+    if ((e->dev_hooks & 4u) && e->kind == GYMRS_CARTPOLE) threads = kBlock; // (developer hook: 256 work-items per workgroup for CartPole chains)
     uint32_t last_key = ~0u;
     AqlKernel k;
     auto bail = [e](gymrs_status st) { // close the chain (what was dispatched still runs and hands the stream back), keep the error
@@ -1229,7 +1234,7 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         // (stream_op_barrier).  The step itself then goes into the open chain, or into a new one behind whatever that was.
         uint32_t flags = 0;
         if (gymrs_status st = flags_for_step(e, &flags)) return bail(st);
-        flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
+        if (!visible) flags = (flags & ~kFlagHintMask) | chain_hint_bits(e); // (chain_hint_bits says why a chain has its own)
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return bail(st);
         if (!e->chain_open) { // (the host side of this step closed the chain: the step opens the next one)
@@ -1247,12 +1252,12 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
         a.xcc_seq = aql_chain_number(e->aql);
         e->chain_first = false;
-        if (no_xcc_check) a.xcc_check = 0u;
+        if (no_xcc_check || visible) a.xcc_check = 0u;
         bool ok = false;
         switch (e->kind) {
-        case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err); break;
-        case GYMRS_MOUNTAIN_CAR: ok = aql_step(e, k, threads, a, e->consts.mc, &err); break;
-        case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err); break;
+        case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err, visible); break;
+        case GYMRS_MOUNTAIN_CAR: ok = aql_step(e, k, threads, a, e->consts.mc, &err, visible); break;
+        case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err, visible); break;
         }
         if (!ok) return bail(fail(GYMRS_EHIP, "AQL dispatcher: " + err));
         e->last_flags = flags;
@@ -1337,10 +1342,13 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
     return GYMRS_OK;
 }
 
-gymrs_status gymrs_sync(gymrs_engine* e)
+} // extern "C"
+
+// Wait for the engine's stream, then look at what a chain may have reported meanwhile: EVERY read-out that synchronises goes through here (gymrs_sync,
+// the host copies, statistics, snapshot, clone, the serde view), so that arrays a tripped chain may have left stale are never handed out with GYMRS_OK
+// (only gymrs_sync used to look).
+gymrs_status stream_sync_checked(gymrs_engine* e)
 {
-    if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
-    HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     std::atomic_thread_fence(std::memory_order_acquire);
     if (e->aql) {
@@ -1353,7 +1361,7 @@ gymrs_status gymrs_sync(gymrs_engine* e)
     }
     if (const uint32_t where = e->err_seen[1]) { // a wavefront of a chain launch found itself on another XCD than the chain's first launch recorded
         e->err_seen[1] = 0;
-        aql_destroy(e->aql); // (the stream is idle: every chain ended with a wait on it)
+        aql_destroy(e->aql, /*discard=*/true); // (the stream is idle: every chain ended with a wait on it; a queue that tripped the check is not handed on)
         e->aql = nullptr;
         char buf[400];
         std::snprintf(buf, sizeof(buf), "a gymrs_step_many chain ran workgroup %u on another XCD than the chain's first launch recorded for its index: the launches of a "
@@ -1362,6 +1370,16 @@ gymrs_status gymrs_sync(gymrs_engine* e)
         e->aql_why = "a chain launch ran on an unexpected XCD; HIP launches from then on";
         return fail(GYMRS_EHIP, buf);
     }
+    return GYMRS_OK;
+}
+
+extern "C" {
+
+gymrs_status gymrs_sync(gymrs_engine* e)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_sync: engine is NULL");
+    HIP_TRY(hipSetDevice(e->device));
+    if (gymrs_status st = stream_sync_checked(e)) return st;
     if (*e->err_seen == 0) return GYMRS_OK; // no kernel saw an invalid action: nothing to fetch
     uint32_t err[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(err, e->err, sizeof(err), hipMemcpyDeviceToHost, e->stream));

@@ -72,13 +72,13 @@ gymrs_status gymrs_get_obs(gymrs_engine* e, uint64_t first, uint64_t count, floa
     int dim = 0;
     gymrs_obs_ptrs(e, ptrs, &dim);
     if (e->pool_host) { // small engine: the arrays ARE host memory (no copy-engine command on the single-env mirror path)
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (gymrs_status st_ = stream_sync_checked(e)) return st_;
         for (int j = 0; j < dim; ++j) std::memcpy(host_out + (size_t)j * count, host_of(e, ptrs[j]) + first, count * sizeof(float));
         return GYMRS_OK;
     }
     for (int j = 0; j < dim; ++j)
         HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, ptrs[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (gymrs_status st_ = stream_sync_checked(e)) return st_;
     return GYMRS_OK;
 }
 
@@ -88,13 +88,13 @@ gymrs_status gymrs_get_state(gymrs_engine* e, uint64_t first, uint64_t count, fl
     if (gymrs_status st = range_check(e, first, count, "gymrs_get_state")) return st;
     HIP_TRY(hipSetDevice(e->device));
     if (e->pool_host) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (gymrs_status st_ = stream_sync_checked(e)) return st_;
         for (int j = 0; j < e->state_dim; ++j) std::memcpy(host_out + (size_t)j * count, host_of(e, e->s[j]) + first, count * sizeof(float));
         return GYMRS_OK;
     }
     for (int j = 0; j < e->state_dim; ++j)
         HIP_TRY(hipMemcpyAsync(host_out + (size_t)j * count, e->s[j] + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (gymrs_status st_ = stream_sync_checked(e)) return st_;
     return GYMRS_OK;
 }
 
@@ -133,7 +133,7 @@ gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t cou
     if (gymrs_status st = range_check(e, first, count, "gymrs_get_step_result")) return st;
     HIP_TRY(hipSetDevice(e->device));
     if (e->pool_host) {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (gymrs_status st_ = stream_sync_checked(e)) return st_;
         if (reward) std::memcpy(reward, host_of(e, e->reward) + first, count * sizeof(float));
         if (done) std::memcpy(done, host_of(e, e->done) + first, count);
         if (truncated) std::memcpy(truncated, host_of(e, e->truncated) + first, count);
@@ -142,7 +142,7 @@ gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t cou
     if (reward) HIP_TRY(hipMemcpyAsync(reward, e->reward + first, count * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     if (done) HIP_TRY(hipMemcpyAsync(done, e->done + first, count, hipMemcpyDeviceToHost, e->stream));
     if (truncated) HIP_TRY(hipMemcpyAsync(truncated, e->truncated + first, count, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (gymrs_status st_ = stream_sync_checked(e)) return st_;
     return GYMRS_OK;
 }
 
@@ -240,7 +240,11 @@ gymrs_status gymrs_engine_clone(gymrs_engine* src, gymrs_engine** out)
         gymrs_engine_destroy(dst);
         return st;
     }
-    hipError_t err = hipStreamSynchronize(src->stream); // everything queued on the source has happened
+    if (gymrs_status st = stream_sync_checked(src)) { // everything queued on the source has happened -- and no chain of it tripped a check
+        gymrs_engine_destroy(dst);
+        return st;
+    }
+    hipError_t err = hipSuccess;
     const std::vector<Segment> from = snapshot_segments(src), to = snapshot_segments(dst);
     for (size_t i = 0; i < from.size() && err == hipSuccess; ++i)
         err = hipMemcpyAsync(to[i].dev, from[i].dev, from[i].bytes, hipMemcpyDefault, dst->stream); // (a small engine's pool is mapped host memory)
@@ -300,7 +304,7 @@ gymrs_status gymrs_snapshot_save(gymrs_engine* e, void* host_buf, uint64_t bytes
         HIP_TRY(hipMemcpyAsync(p, sg.dev, sg.bytes, hipMemcpyDefault, e->stream));
         p += sg.bytes;
     }
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (gymrs_status st_ = stream_sync_checked(e)) return st_;
     return GYMRS_OK;
 }
 
@@ -364,7 +368,7 @@ gymrs_status gymrs_stats(gymrs_engine* e, double out[4])
     if (!e || !out) return fail(GYMRS_EINVAL, "gymrs_stats: NULL argument");
     double* dev = nullptr;
     if (gymrs_status st = gymrs_stats_device(e, &dev)) return st;
-    HIP_TRY(hipStreamSynchronize(e->stream)); // the read-out kernel has written the four doubles into mapped host memory
+    if (gymrs_status st_ = stream_sync_checked(e)) return st_; // the read-out kernel has written the four doubles into mapped host memory
     std::atomic_thread_fence(std::memory_order_acquire);
     for (int j = 0; j < 4; ++j) out[j] = e->stats_host[j];
     return GYMRS_OK;
@@ -626,13 +630,13 @@ gymrs_status gymrs_env_json(gymrs_engine* e, uint64_t lane, char* buf, uint64_t 
     float st[4] = {0, 0, 0, 0};
     uint8_t beyond = 0;
     if (e->pool_host) { // small engine: plain loads from the mapped pool
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (gymrs_status st_ = stream_sync_checked(e)) return st_;
         for (int j = 0; j < e->state_dim; ++j) st[j] = host_of(e, e->s[j])[lane];
         if (e->kind == GYMRS_CARTPOLE) beyond = host_of(e, e->beyond)[lane];
     } else {
         for (int j = 0; j < e->state_dim; ++j) HIP_TRY(hipMemcpyAsync(&st[j], e->s[j] + lane, sizeof(float), hipMemcpyDeviceToHost, e->stream));
         if (e->kind == GYMRS_CARTPOLE) HIP_TRY(hipMemcpyAsync(&beyond, e->beyond + lane, 1, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (gymrs_status st_ = stream_sync_checked(e)) return st_;
     }
     double low[4], high[4];
     int dim = 0;
@@ -781,6 +785,16 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* text, void*
     }
     if (state_dim) *state_dim = dim;
     if (bad) return fail(GYMRS_EINVAL, "gymrs_params_from_json: a known field has the wrong JSON type");
+    return GYMRS_OK;
+}
+
+// Test / developer hooks of the chain path (NOT in the header; tests/test_gpu_aql_chain.py and A/B tools bind it by name): bit 0 the next chains
+// find a poisoned XCD table (stands in for a workgroup deal that changed under the engine), bit 1 no XCD check (what it costs), bit 2 CartPole chains
+// with 256 work-items per workgroup.  Until round 4 these were environment variables read on every gymrs_step_many.
+gymrs_status gymrs_dev_set_hooks(gymrs_engine* e, uint32_t bits)
+{
+    if (!e) return fail(GYMRS_EINVAL, "gymrs_dev_set_hooks: engine is NULL");
+    e->dev_hooks = bits;
     return GYMRS_OK;
 }
 

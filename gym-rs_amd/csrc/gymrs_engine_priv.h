@@ -153,6 +153,7 @@ struct gymrs_engine {
     // under GYMRS_AQL=0, by the first gymrs_step_many that can use it); aql_why says why not when it stays NULL.
     AqlChain* aql = nullptr;
     bool aql_tried = false;
+    uint32_t dev_hooks = 0;  // gymrs_dev_set_hooks (test / developer hooks of the chain path; 0 in production)
     bool chain_open = false; // gymrs_step_many is inside aql_begin .. aql_end: see stream_op_barrier
     bool chain_first = false; // the next step launch is the first of the open chain: it records the XCD table (StepArgs::xcc_table)
     std::string aql_why, aql_handover;
@@ -193,6 +194,7 @@ inline T* host_of(const gymrs_engine* e, T* dev)
 // defined in gymrs_engine.hip
 GYMRS_HOST_INTERNAL StatsArgs stats_args(const gymrs_engine* e);
 GYMRS_HOST_INTERNAL gymrs_status fold_reset_log(gymrs_engine* e);
+GYMRS_HOST_INTERNAL gymrs_status stream_sync_checked(gymrs_engine* e); // hipStreamSynchronize + what a chain reported meanwhile
 GYMRS_HOST_INTERNAL void limit_restart(gymrs_engine* e, uint64_t bound, bool trunc_zero);
 GYMRS_HOST_INTERNAL std::string aql_kernel_name(const gymrs_engine* e, uint32_t flags, int threads);
 // defined in gymrs_engine_io.hip (RCCL is resolved there, at first use)

@@ -162,16 +162,15 @@ gymrs_status gymrs_sharded_create(gymrs_env_kind kind, uint64_t n_total, uint64_
     h->n_total = n_total;
     h->gid0 = global_env_offset;
     h->flags = flags;
-    // Contiguous blocks; every block but the last a whole number of 1024-lane tiles, so that every shard's arrays start where a tile of the
-    // unsharded batch starts (nothing depends on it -- lanes are independent --, it only keeps ragged tails to the last block).
+    // Contiguous blocks; every block but the last a whole number of 1024-lane tiles (n_total / n_shards rounded DOWN to tiles), the last takes
+    // the rest: every block's arrays start where a tile of the unsharded batch starts, and the ragged tail stays in the last block.  (Nothing
+    // depends on it -- lanes are independent.)
     const uint64_t tile = 1024;
-    uint64_t per = (n_total + (uint64_t)n_shards - 1) / (uint64_t)n_shards;
-    if (per >= tile) per = (per + tile - 1) / tile * tile;
+    uint64_t per = n_total / (uint64_t)n_shards;
+    if (per >= tile) per = per / tile * tile;
     uint64_t first = 0;
     for (int r = 0; r < n_shards; ++r) {
-        const uint64_t left = n_total - first;
-        const uint64_t shards_left = (uint64_t)(n_shards - r);
-        uint64_t count = r == n_shards - 1 ? left : (per < left - (shards_left - 1) ? per : left - (shards_left - 1)); // >= 1 lane for every later shard
+        const uint64_t count = r == n_shards - 1 ? n_total - first : per;
         Worker* wk = new Worker();
         wk->index = r;
         wk->device = devices ? devices[r] : r;

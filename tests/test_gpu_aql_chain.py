@@ -273,10 +273,11 @@ def test_full_size_chain_is_faster(gymrs):
 
 def test_a_chain_launch_on_an_unexpected_xcd_is_loud(gymrs, twin):
     """The launches of a chain carry no release fence, which is only right while workgroup i runs on the same XCD in every launch.  The
-    dispatcher's self-check reads the deal from the hardware once per device; EVERY production launch of a chain then compares the
-    XCC it runs on (HW_REG_XCC_ID) with that table (step_kernel_body, StepArgs::xcc_map).  A table rotated by one entry (test hook
-    GYMRS_AQL_TEST_WRONG_XCC=1) stands in for a deal that changed under the engine: gymrs_sync must fail with GYMRS_EHIP, and the
-    engine must go on through HIP launches (VERDICT r3 "next" #3)."""
+    FIRST launch of every chain records, per residue class of the workgroup index (mod 8), the XCC it runs on (HW_REG_XCC_ID) into the chain
+    object's own table, tagged with the chain's number (StepArgs::xcc_table); every later launch of that chain compares.  A table nobody's
+    XCC matches -- and no recording launch -- (test hook gymrs_dev_set_hooks bit 0: the table is overwritten on the stream ahead of the chain)
+    stands in for a deal that changed under the engine: gymrs_sync must fail with GYMRS_EHIP, the chain object is DISCARDED (not parked for the
+    next engine) and the engine goes on through HIP launches (VERDICT r3 "next" #3)."""
     n, nbuf = 20_000, 4
     flags = flags_of(gymrs, 0)
     with aql(True):
@@ -286,14 +287,20 @@ def test_a_chain_launch_on_an_unexpected_xcd_is_loud(gymrs, twin):
             eng.step_many(ring.data_ptr(), n, nbuf, 16)
             eng.sync()  # the true table: silent
             assert extras(eng)["aql"] == "on" and extras(eng)["aql_launches"] == 16
-            os.environ["GYMRS_AQL_TEST_WRONG_XCC"] = "1"
+            import ctypes as C
+
+            lib = gymrs.load_library()
+            lib.gymrs_dev_set_hooks.argtypes = [C.c_void_p, C.c_uint32]
+            assert lib.gymrs_dev_set_hooks(eng._h, 1) == 0
             try:
                 eng.step_many(ring.data_ptr(), n, nbuf, 16)
+                # EVERY read-out that synchronises reports it, not only gymrs_sync: here the first one after the chain is a host copy
                 with pytest.raises(gymrs.GymrsError, match="another XCD") as info:
-                    eng.sync()
+                    eng.get_state()
                 assert info.value.status == 2  # GYMRS_EHIP
+                eng.sync()  # reported once
             finally:
-                os.environ.pop("GYMRS_AQL_TEST_WRONG_XCC", None)
+                assert lib.gymrs_dev_set_hooks(eng._h, 0) == 0
             x = extras(eng)
             assert x["aql"] != "on" and "XCD" in x["aql"] and x["aql_launches"] == 32, x
             eng.step_many(ring.data_ptr(), n, nbuf, 16)  # HIP launches from here on

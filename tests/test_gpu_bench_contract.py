@@ -134,6 +134,9 @@ def test_the_drivers_own_command_prints_a_well_formed_line(driver_line):
     assert d["episodes"]["n_episodes"] > 0
     pm = d["roofline"]["peak_measured"]
     assert 3000 < pm["hbm_copy_GBps"] < 8000
+    if d["paths"]["chain"]["submission"].startswith("AQL chains"):  # the per-step-visible shape once more, submitted through the engine's queue with HIP's header
+        assert 2.0 < d["roofline"]["queue_launch_us"] < 12.0 and d["_line"]["roofline"]["queue_launch_us"] == pytest.approx(d["roofline"]["queue_launch_us"], rel=1e-5)
+        assert all(c["roofline"]["queue_launch_us"] > 0 for c in cfgs.values())
     print("submission:", {k: v["submission"] for k, v in d["paths"].items()})
 
 
@@ -205,7 +208,7 @@ def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     env = dict(os.environ, GYMRS_BENCH_PASSES="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
     two = run([sys.executable, "bench.py", "--gpus", "2", "--oversubscribe", "--n-envs", "100000", *common], env=env)
     check_common(two, 2, 40, 10, min_ms=0.0, min_frac=0.0)  # GYMRS_BENCH_PASSES pins the work so that the two runs are comparable
-    assert two["oversubscribed"] and two["config"]["stats_allreduce"] == "torch.distributed(gloo)"
+    assert two["oversubscribed"] and two["config"]["stats_allreduce"] == "torch.distributed(gloo)" and two["sharder"] == "process-per-gpu"
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", "200000", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == two["timing"]["passes_per_repetition"] == 3
     assert one["timing"]["calibration_passes"] == two["timing"]["calibration_passes"]
@@ -235,6 +238,25 @@ def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     assert one["timing"]["passes_per_repetition"] == eight["timing"]["passes_per_repetition"] == 2
     assert one["timing"]["calibration_passes"] == eight["timing"]["calibration_passes"]
     assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0
+
+
+@pytest.mark.parametrize("blocks", [1, 4])
+def test_in_process_form_runs_the_native_sharder(blocks):
+    """`bench.py --in-process --gpus N`: ONE process, the C ABI's own sharder (gymrs_sharded_*: one engine + one native host thread per block) instead of
+    one process per GPU -- same line, `sharder` says which form ran (VERDICT r4 "next" #3).  On a one-GPU box N = 4 blocks share the GPU (TEST mode)."""
+    extra = ["--oversubscribe"] if blocks > torch.cuda.device_count() else []
+    d = run([sys.executable, "bench.py", "--in-process", "--gpus", str(blocks), "--steps", "50", "--warmup", "10", "--cpu-seconds", "0", "--n-envs", str(1 << 18),
+             "--min-repetition-ms", "5", "--repetitions", "5", *extra])
+    assert d["sharder"] == "in-process" and d["_line"]["sharder"] == "in-process" and d["n_gpus"] == blocks
+    assert d["config"]["total_lanes"] == blocks << 18 and len(d["ranks"]) == blocks
+    assert [r["global_env_offset"] for r in d["ranks"]] == [r << 18 for r in range(blocks)]
+    assert d["value"] == pytest.approx(d["config"]["total_lanes"] / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["config"]["stats_allreduce"].startswith("gymrs_sharded_stats") and d["episodes"]["n_episodes"] > 0
+    assert ("oversubscribed" in d) == bool(extra)
+    assert 0 < d["roofline"]["frac"] <= 1.0 and d["roofline"]["bound"] == "hbm"
+    one = run([sys.executable, "bench.py", "--gpus", "1", "--steps", "50", "--warmup", "10", "--cpu-seconds", "0", "--no-probe", "--n-envs", str(1 << 18),
+               "--min-repetition-ms", "5", "--repetitions", "5"])
+    assert one["sharder"] == "single engine"
 
 
 @pytest.mark.parametrize("env_name", ["mountain_car", "pendulum"])

@@ -42,7 +42,7 @@ def test_k_blocks_equal_one_engine(gymrs, kind, n, k):
     sh = gymrs.ShardedEngine(kind, n, devices_for(k), flags=flags)
     assert len(sh.shards) == k and sum(s.n_envs for s in sh.shards) == n
     assert [s.first_lane for s in sh.shards] == list(np.cumsum([0] + [s.n_envs for s in sh.shards[:-1]]))
-    assert all(s.n_envs % 1024 == 0 for s in sh.shards[:-1]) or n < 1024 * k  # ragged tails are kept to the last block
+    assert all(s.n_envs % 1024 == 0 and s.n_envs == sh.shards[0].n_envs for s in sh.shards[:-1]) and sh.shards[-1].n_envs >= sh.shards[0].n_envs  # the ragged tail stays in the last block
     one = gymrs.BatchedEngine(kind, n, flags=flags, device=0)
     sh.reset(seed=11)
     one.reset(seed=11)

@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--ring-2d", type=int, default=0)
     ap.add_argument("--wall", type=int, default=0, help="host wall clock (call + sync) instead of stream events")
     ap.add_argument("--all", type=int, default=0, help="print every repetition")
+    ap.add_argument("--aql", default="", help="comma-separated GYMRS_AQL values (0 HIP launches, 1 chains, 2 the queue with HIP's header on every launch): "
+                                              "one engine per (library, hint, value), timed alternately; default: the environment's")
     ap.add_argument("--nbuf", type=int, default=32, help="action buffers in the ring (32 = bench.py's default)")
     args = ap.parse_args()
     libs = [Lib(p) for p in (args.lib or [ROOT / "gym-rs_amd" / "libgymrs_amd.so"])]
@@ -67,9 +69,18 @@ def main():
         ring = torch.empty(nbuf * args.n * esz, dtype=torch.uint8, device="cuda:0")
     engines = []
     handles = []
-    nts = [int(x) for x in args.nts.split(",") if x] or [args.nt]
+    import os
+
+    aqls = [x for x in args.aql.split(",") if x] or [None]
+    nts = [(int(x), q) for x in (args.nts.split(",") if args.nts else [str(args.nt)]) if x for q in aqls]
     libs = [lb for lb in libs for _ in nts]
-    modes = [nt for _ in range(len(libs) // len(nts)) for nt in nts]
+    both = [m for _ in range(len(libs) // len(nts)) for m in nts]
+    modes = [m[0] for m in both]
+    aql_of = [m[1] for m in both]
+
+    def with_aql(q):
+        if q is not None:
+            os.environ["GYMRS_AQL"] = q
     for lb in libs:
         h = C.c_void_p()
         lb.ck(lb.lib.gymrs_engine_create(args.env, args.n, 0, 0, None, flags, C.byref(h)))
@@ -87,14 +98,16 @@ def main():
         s = C.c_void_p()
         lb.ck(lb.lib.gymrs_get_stream(h, C.byref(s)))
         engines.append((lb, h, torch.cuda.ExternalStream(s.value, device="cuda:0")))
-    keys = [f"{lb.path} nt={nt}" for lb, nt in zip(libs, modes)]
+    keys = [f"{lb.path} nt={nt}" + (f" GYMRS_AQL={q}" if q is not None else "") for lb, nt, q in zip(libs, modes, aql_of)]
     times = {k: [] for k in keys}
     host = {k: [] for k in keys}
-    for lb, h, st in engines:  # warm-up (clocks, caches)
+    for (lb, h, st), q in zip(engines, aql_of):  # warm-up (clocks, caches)
+        with_aql(q)
         lb.ck(lb.lib.gymrs_step_many(h, ring.data_ptr(), args.n * esz, nbuf, min(2000, args.steps), args.graph))
         lb.ck(lb.lib.gymrs_sync(h))
     for _ in range(args.reps):
-        for key, (lb, h, st) in zip(keys, engines):
+        for key, (lb, h, st), q in zip(keys, engines, aql_of):
+            with_aql(q)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(st)
             w0 = time.perf_counter()
