@@ -246,6 +246,7 @@ def parse_args(argv=None):
     ap.add_argument("--min-repetition-ms", type=float, default=MIN_REPETITION_SECONDS * 1e3,
                     help="a timed repetition lasts at least this long (default 100: the sustained rate, see MIN_REPETITION_SECONDS; runs under a profiler use 5)")
     ap.add_argument("--no-probe", action="store_true", help="skip the in-process copy-kernel probe (roofline.peak_measured)")
+    ap.add_argument("--no-queue-shape", action="store_true", help="skip the extra measurement of the per-step-visible shape through the engine's queue (roofline.queue_launch_us)")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the short legs for the other BASELINE configs (MountainCar 2^20, Pendulum 2^22, CartPole 2^24) that "
                          "the default N=1 CartPole run attaches as `configs`")
@@ -398,7 +399,7 @@ def measure_pmc_traffic(args, env_name: str, sha: str):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = Path(tmp) / ctr
             cmd = ["rocprofv3", "--pmc", ctr, "-d", str(d), "-o", "r", "--", sys.executable, str(ROOT / "bench.py"), "--env", env_name,
-                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--repetitions", "2", "--min-repetition-ms", "5"]
+                   "--steps", "100", "--warmup", "20", "--cpu-seconds", "0", "--no-probe", "--no-configs", "--no-queue-shape", "--repetitions", "2", "--min-repetition-ms", "5"]
             if args.n_envs:
                 cmd += ["--n-envs", str(args.n_envs)]
             if args.vec:
@@ -764,7 +765,8 @@ def run_rank(args, info, backend, make_collective=None):
                 out["mode"] = "hip_graph_replays"
                 launch_us = kernel_ms * 1e3 / steps_timed
                 out["roofline"] = roofline_of("per_step_visible", n, bytes_per_step, launch_us, None, "graph replays: no committed traffic figure", extras().get("last_launch"), sha)
-    if info.is_root and info.world == 1 and backend.name == "hip" and per_step and HEADLINE_PATH in (out.get("paths") or {}) and hasattr(eng, "env_json"):
+    if (info.is_root and info.world == 1 and backend.name == "hip" and per_step and HEADLINE_PATH in (out.get("paths") or {}) and hasattr(eng, "env_json")
+            and not args.no_queue_shape):
         q_us = measure_visible_through_queue(backend, eng, stream, act_ptr, act_stride, nbuf, args.steps * max(1, passes // 5))
         if q_us:
             out["paths"][HEADLINE_PATH]["roofline"]["queue_launch_us"] = q_us  # (the same dict object as out["roofline"] when the headline is this shape)

@@ -132,7 +132,10 @@ struct ResetArgs {
 // ... and only while the launch is at most two generations of waves: from 2^22 lanes on a CU refills better in units of 4 waves (round 4,
 // profiles/r04_wave_variants.log: 2^22 lanes 25.7 -> 24.8 us, 2^23 48.7 -> 47.4; 2^21 12.0 vs 12.2 the other way).
 constexpr int kCartPoleThreads = 512;
-constexpr uint64_t kBigGroupsFrom = 512, kBigGroupsBelow = 2048;
+#ifndef GYMRS_EXP_BIG_BELOW // (developer builds: where the 512-work-item window of CartPole ends; profiles/r05_cartpole_2p21.log)
+#define GYMRS_EXP_BIG_BELOW 2048
+#endif
+constexpr uint64_t kBigGroupsFrom = 512, kBigGroupsBelow = GYMRS_EXP_BIG_BELOW;
 inline bool step_uses_big_groups(uint64_t n, int threads, int vec)
 {
     return n >= (uint64_t)threads * vec * kBigGroupsFrom && n < (uint64_t)threads * vec * kBigGroupsBelow;

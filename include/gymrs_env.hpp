@@ -116,7 +116,7 @@ public:
         check(gymrs_sync(e_));
     }
     // n_steps consecutive steps, step t with the actions of buffer t % n_buffers of a ring of device buffers stride_bytes apart; one
-    // asynchronous call (8 steps and more: one chain through the engine's own HSA queue, DESIGN.md 3.7)
+    // asynchronous call (8 steps and more: one chain through the engine's own HSA queue, DESIGN.md 3.2)
     void step_many(const void* actions_dev, std::uint64_t stride_bytes, std::uint32_t n_buffers, std::uint32_t n_steps, bool use_graph = false)
     {
         check(gymrs_step_many(e_, actions_dev, stride_bytes, n_buffers, n_steps, use_graph ? 1 : 0));

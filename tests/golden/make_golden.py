@@ -236,6 +236,34 @@ def main():
         ph["resets"]["pendulum"].append({"seed": seed, "gid": gid, "tick": tick,
                                          "state": [uniform_between(r[0], -math.pi, math.pi), uniform_between(r[1], -1.0, 1.0)]})
 
+    # ---- single steps from f32-REPRESENTABLE states (round 5): the GPU holds its state in f32, so a fixture whose inputs are exact
+    #      in f32 lets the GPU test hold north_star's 1e-6 itself instead of 5e-6 (input rounding amplified by |d next / d state| ~ 20).  A second
+    #      generator: the vectors above stay what they were.  Evaluated in f64 like everything else here.
+    import struct
+
+    def f32(x):
+        return struct.unpack("<f", struct.pack("<f", x))[0]
+
+    r32 = random.Random(20260929)
+    cp["single_steps_f32_inputs"] = []
+    for _ in range(512):
+        st = tuple(f32(v) for v in (r32.uniform(-2.4, 2.4), r32.uniform(-3, 3), r32.uniform(-0.21, 0.21), r32.uniform(-3, 3)))
+        a = r32.randrange(2)
+        s, r, d, _ = cartpole_step(st, a, False)
+        cp["single_steps_f32_inputs"].append({"state": st, "action": a, "next": s, "reward": r, "done": d})
+    mc["single_steps_f32_inputs"] = []
+    for _ in range(512):
+        st = (f32(r32.uniform(-1.2, 0.6)), f32(r32.uniform(-0.07, 0.07)))
+        a = r32.randrange(3)
+        s, r, d = mountain_car_step(st, a)
+        mc["single_steps_f32_inputs"].append({"state": st, "action": a, "next": s, "reward": r, "done": d})
+    pd["single_steps_f32_inputs"] = []
+    for _ in range(512):
+        st = (f32(r32.uniform(-math.pi, math.pi) + r32.choice([0, 0, 10 * math.pi, -37.0])), f32(r32.uniform(-8, 8)))
+        a = f32(r32.uniform(-2.5, 2.5))
+        ns, obs, rew = pendulum_step(st, a)
+        pd["single_steps_f32_inputs"].append({"state": st, "action": a, "next": ns, "obs": obs, "reward": rew})
+
     # ---- the reference's own unit tests, as data (spaces/discrete.rs:27-41, util_fns.rs:16-32,
     #      seeding.rs:33-39 + doctest seeding.rs:11-20) ----
     pins = {

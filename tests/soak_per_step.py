@@ -31,7 +31,7 @@ for chunk, graph in ((10001, False), (20000, True), (9999, False)):
 print("per-step soak ok:", done, "steps", eng.stats(), f"{time.time()-t0:.1f}s")
 
 # The same with all three flags and a 45-step time limit that random-policy episodes reach now and then: launches with and
-# without the limit alternate (GYMRS_TIME_LIMIT elision), refreshes of the bound with back-off,
+# without the limit alternate (GYMRS_TIME_LIMIT elision, docs/history/DESIGN_rounds_1-4.md 3.1 item 6b), refreshes of the bound with back-off,
 # graph replays (which keep the limit) in the middle.
 import json
 p = gymrs.engine.default_params(0)

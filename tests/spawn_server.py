@@ -1,7 +1,7 @@
 """Children of the test process are started by a helper that never loads the HIP runtime.
 
 `fork()` in a process whose HIP / HSA runtime is up (helper threads, signal handlers, queues mapped from the driver) is the one thing the
-round-4 GPU suite ever died of: one run in ~50 ended with a segmentation fault inside `subprocess.run`, never
+round-4 GPU suite ever died of: one run in ~50 ended with a segmentation fault inside `subprocess.run` ("Suite soak"), never
 reproduced under a native-backtrace handler.  `start()` is called when conftest.py is imported -- before torch is, so before any HIP
 call -- and forks ONE plain python child; `run()` has `subprocess.run`'s signature and hands the command to that child, which runs it
 with `subprocess.run` and sends the result (or the exception) back.  Without `start()` (or if the helper died) `run()` is

@@ -71,6 +71,14 @@ def test_no_cpu_fallback_without_gpu(gymrs):
     assert "no CPU fallback" in str(exc.value) or "HIP" in str(exc.value)
     with pytest.raises(gymrs.GymrsError):
         gymrs.CartPoleEnv()
+    # the in-process sharder (ABI 3) too: its worker threads start, the first block's engine cannot be created, everything is torn down again and
+    # the caller's thread gets the WORKER's message with the shard and its device in front (the error string is per thread in the library)
+    with pytest.raises(gymrs.GymrsError) as exc:
+        gymrs.ShardedEngine(gymrs.CARTPOLE, 4096, [0, 1])
+    assert "shard 0 (device 0)" in str(exc.value) and "no CPU fallback" in str(exc.value)
+    lib = gymrs.load_library()
+    out = (C.c_double * 4)()
+    assert lib.gymrs_allreduce_stats_multi(None, 2, out, None) == 1 and lib.gymrs_sharded_stats(None, out) == 1 and lib.gymrs_sharded_sync(None) == 1
 
 
 def test_bad_arguments_are_status_codes_not_crashes(gymrs):

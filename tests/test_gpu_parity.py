@@ -220,6 +220,38 @@ def test_step_many_graph_refused_for_pendulum_time_limit(gymrs):
     eng.close()
 
 
+def test_golden_vectors_with_f32_inputs_on_gpu_hold_1e_6(gymrs, golden):
+    """north_star's bar on committed fixtures: `single_steps_f32_inputs` = 512 single steps per env whose input states are EXACT in
+    f32 (tests/golden/make_golden.py, evaluated in f64 from the reference's source text), so nothing is lost handing them to the engine and the result is held
+    to 1e-6 relative (to max(|ref|, 1)) -- the f64-input fixtures below need 5e-6 because their inputs are rounded on the way in."""
+    for kind, name in ((0, "cartpole"), (1, "mountain_car"), (2, "pendulum")):
+        cases = golden(name)["single_steps_f32_inputs"]
+        st = np.array([c["state"] for c in cases], np.float64).T
+        assert np.array_equal(st.astype(np.float32).astype(np.float64), st)  # exact in f32
+        act = np.array([c["action"] for c in cases], np.float32 if kind == 2 else np.uint8)
+        with gymrs.BatchedEngine(kind, len(cases)) as eng:
+            eng.set_state(st.astype(np.float32))
+            eng.step_host(act)
+            got = eng.get_state()
+            reward, done, _ = eng.get_step_result()
+            obs = eng.get_obs()
+        want = np.array([c["next"] for c in cases]).T
+        assert mixed_err(got, want).max() <= 1e-6, (name, mixed_err(got, want).max())
+        if kind == 0:
+            # the flag is the reference's compare of the state the engine holds: exact wherever the f64 result is not within f32 rounding of a threshold
+            far = np.array([abs(abs(c["next"][0]) - 2.4) > 1e-5 and abs(abs(c["next"][2]) - 0.20943951023931953) > 1e-6 for c in cases])
+            assert far.sum() > 450 and np.array_equal(done[far].astype(bool), np.array([c["done"] for c in cases])[far])
+            assert np.array_equal(reward, np.ones(len(cases), np.float32))  # cartpole.rs:455-459: 1.0 on the step that terminates too
+        elif kind == 1:
+            far = np.array([abs(c["next"][0] - 0.5) > 1e-6 for c in cases])
+            assert np.array_equal(done[far].astype(bool), np.array([c["done"] for c in cases])[far]) and (reward == -1.0).all()
+        else:
+            want_obs = np.array([c["obs"] for c in cases]).T
+            scale = np.maximum(np.abs(want[0]), 1.0)  # cos / sin inherit the f32 representation error of the new theta (up to ~40 rad here)
+            assert (np.abs(obs.astype(np.float64) - want_obs) / scale).max() <= 1e-6
+            assert mixed_err(reward, np.array([c["reward"] for c in cases])).max() <= 1e-6
+
+
 def test_golden_vectors_on_gpu(gymrs, golden):
     cp = golden("cartpole")
     cases = cp["single_steps"]

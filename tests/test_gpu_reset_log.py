@@ -1,4 +1,4 @@
-"""The reset log: CartPole engines with GYMRS_TRACK_STATS and without GYMRS_TIME_LIMIT keep their
+"""The reset log (docs/history/DESIGN_rounds_1-4.md §3.1 item 6): CartPole engines with GYMRS_TRACK_STATS and without GYMRS_TIME_LIMIT keep their
 episode bookkeeping as done-mask rows in an 8-row ring that every 8th launch folds inside the kernel, and that a
 stand-alone kernel folds on demand.  Whatever the host does between two steps -- reading statistics at any phase of the
 ring, changing the launch shape, replaying captured graphs, running the fused rollout, cloning, snapshotting,

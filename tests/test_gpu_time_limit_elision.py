@@ -1,4 +1,4 @@
-"""GYMRS_TIME_LIMIT elision: with all three flags a CartPole launch runs WITHOUT the time limit
+"""GYMRS_TIME_LIMIT elision (docs/history/DESIGN_rounds_1-4.md §3.1 item 6b): with all three flags a CartPole launch runs WITHOUT the time limit
 -- the reset-logged headline kernel -- whenever the host can prove that no lane reaches the limit
 in that step (every open episode started at or after `start_bound`, refreshed asynchronously from the age of the oldest
 episode).  Nothing observable may change: states, rewards, done / truncated flags and statistics stay bit-identical to the

@@ -27,7 +27,9 @@ def test_cartpole_constants(golden, oracle):
 
 
 def test_cartpole_single_steps(golden, oracle):
-    for case in golden("cartpole")["single_steps"]:
+    cp = golden("cartpole")
+    assert len(cp["single_steps_f32_inputs"]) == 512  # (round 5: states exact in f32, for the GPU's 1e-6 test; same evaluation, same bound here)
+    for case in cp["single_steps"] + cp["single_steps_f32_inputs"]:
         e = CartPoleEnv(*case["state"], 0, 0)
         rc, r = oracle.cartpole_step(e, case["action"])
         assert rc == 0
@@ -100,7 +102,7 @@ def test_mountain_car_single_steps_and_wall(golden, oracle):
     p = oracle.mountain_car_params()
     for k, v in golden("mountain_car")["constants"].items():
         assert getattr(p, k) == v
-    for case in golden("mountain_car")["single_steps"]:
+    for case in golden("mountain_car")["single_steps"] + golden("mountain_car")["single_steps_f32_inputs"]:
         e = MountainCarEnv(*case["state"])
         rc, r = oracle.mountain_car_step(e, case["action"])
         assert rc == 0
@@ -129,7 +131,7 @@ def test_mountain_car_trajectory(golden, oracle):
 def test_pendulum_spec_vectors(golden, oracle):
     """Spec-derived (Gym Pendulum-v1), not reference data: parity unpinned."""
     pd = golden("pendulum")
-    for case in pd["single_steps"]:
+    for case in pd["single_steps"] + pd["single_steps_f32_inputs"]:
         e = PendulumEnv(*case["state"])
         _, r = oracle.pendulum_step(e, case["action"])
         assert [e.theta, e.theta_dot] == pytest.approx(case["next"], rel=1e-15, abs=1e-15)

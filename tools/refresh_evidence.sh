@@ -4,7 +4,7 @@
 #   gpurun --timeout 3000 -- 'bash tools/refresh_evidence.sh r04'
 # Counter passes are separate runs without any trace domain besides the counters (gpurun refuses mixes).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -22,20 +22,24 @@ cp "$OUT/${TAG}_devcount_traffic.json" profiles/devcount_traffic.json
 
 # 2. per-dispatch PMC (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one counter per pass) of the same kernels: each launch in isolation
 for env in cartpole mountain_car pendulum; do
-    timeout 900 python bench.py --env $env --pmc-traffic --cpu-seconds 0 --no-probe --no-configs > "$OUT/${TAG}_bench_pmc_${env}.json" 2> "$OUT/${TAG}_bench_pmc_${env}.err"
+    timeout 900 python bench.py --env $env --pmc-traffic --cpu-seconds 0 --no-probe --no-configs --full-out "$OUT/${TAG}_bench_pmc_${env}_full.json" > "$OUT/${TAG}_bench_pmc_${env}.json" 2> "$OUT/${TAG}_bench_pmc_${env}.err"
 done
 cp profiles/pmc_traffic.json "$OUT/${TAG}_pmc_traffic.json"
 
 # 3. the bench lines: the driver's own command, the default form per env
-timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_form.json" 2> "$OUT/${TAG}_bench_driver_form.err"
+# (since round 5 stdout carries the <= 4 KB digest the driver keeps; the complete record goes to --full-out)
+timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --full-out "$OUT/${TAG}_bench_driver_form_full.json" > "$OUT/${TAG}_bench_driver_form.json" 2> "$OUT/${TAG}_bench_driver_form.err"
 for env in cartpole mountain_car pendulum; do
-    timeout 900 python bench.py --env $env > "$OUT/${TAG}_bench_${env}.json" 2> "$OUT/${TAG}_bench_${env}.err"
+    timeout 900 python bench.py --env $env --full-out "$OUT/${TAG}_bench_${env}_full.json" > "$OUT/${TAG}_bench_${env}.json" 2> "$OUT/${TAG}_bench_${env}.err"
 done
+# 3b. the same workload through the C ABI's native in-process sharder (one block on this box's one GPU; 4 blocks sharing it: a TEST of the path, not a rate)
+timeout 600 python bench.py --in-process --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --full-out "$OUT/${TAG}_bench_in_process_full.json" > "$OUT/${TAG}_bench_in_process.json" 2> "$OUT/${TAG}_bench_in_process.err"
+timeout 600 python bench.py --in-process --gpus 4 --oversubscribe --n-envs 262144 --steps 20 --warmup 5 --cpu-seconds 0 --full-out "$OUT/${TAG}_bench_in_process_4_blocks_one_gpu_full.json" > "$OUT/${TAG}_bench_in_process_4_blocks_one_gpu.json" 2> "$OUT/${TAG}_bench_in_process_4.err"
 
 # 4. kernel trace of the bench command (both call shapes run in it); the step kernels' (start, end) rows are kept as CSV
 cd /tmp
 rm -rf "$OUT/${TAG}_kt"
-timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -o r -- python "$REPO/bench.py" --steps 1000 --warmup 200 --cpu-seconds 0 --no-probe --no-configs --min-repetition-ms 5 \
+timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/${TAG}_kt" -o r -- python "$REPO/bench.py" --steps 1000 --warmup 200 --cpu-seconds 0 --no-probe --no-configs --min-repetition-ms 5 --full-out "$OUT/${TAG}_bench_cartpole_under_rocprof_full.json" \
     > "$OUT/${TAG}_bench_cartpole_under_rocprof.json" 2> "$OUT/${TAG}_kt.err"
 DB=$(find $OUT/${TAG}_kt -name '*_results.db' | head -1)
 python "$REPO/tools/summarize_rocprof.py" kernel "$DB" "$OUT/${TAG}_kernel_trace_stats_cartpole.txt" > /dev/null
@@ -48,7 +52,8 @@ with gzip.open(sys.argv[2], "wt") as f:
     for n, s, e in rows:
         f.write(f"{n.split('(')[0][:60]},{s},{e}\n")
 with open(sys.argv[3], "w") as f:
-    for label, pred in (("per_step_visible (HIP launches)", lambda n: "step_kernel" in n), ("chain", lambda n: n.startswith("gymrs_aql_cartpole"))):
+    for label, pred in (("per_step_visible (HIP launches)", lambda n: "step_kernel" in n), ("chain", lambda n: n.startswith("gymrs_aql_cartpole") and not n.startswith("gymrs_aql_cartpole_f3_t512_nt")),
+                        ("per_step_visible through the engine's queue (GYMRS_AQL=2)", lambda n: n.startswith("gymrs_aql_cartpole_f3_t512_nt"))):
         ks = [(s, e) for n, s, e in rows if pred(n)]
         if len(ks) < 50:
             continue
@@ -88,4 +93,11 @@ for env in 0 1 2; do
         GYMRS_AQL=$aql timeout 900 python tools/size_sweep.py --env $env --sizes $sizes >> "$OUT/${TAG}_size_sweep_env${env}_aql$aql.log" 2>&1
     done
 done
+# 7. the per-step-visible shape through HIP launches / chains / the engine's queue with HIP's header, by env and size (VERDICT r4 "next" #4)
+L="$OUT/${TAG}_submission_by_size.log"
+: > "$L"
+for env in 0 1 2; do for lg in 20 21 22; do
+    echo "# env $env 2^$lg lanes, 8 action buffers" >> "$L"
+    timeout 600 python tools/step_timer.py --env $env --n $((1<<lg)) --steps $((lg == 20 ? 16000 : 6000)) --reps 5 --aql 0,1,2 --nbuf 8 2>&1 | grep "us median" >> "$L"
+done; done
 echo refresh-done
