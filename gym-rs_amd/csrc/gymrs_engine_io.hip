@@ -494,13 +494,15 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
         if (int rc = g_rccl.GetUniqueId(&uid)) return nccl_fail("ncclGetUniqueId", rc);
         if (int rc = g_rccl.GroupStart()) return nccl_fail("ncclGroupStart", rc);
         int bad = 0;
-        for (int r = 0; r < n && !bad; ++r) {
-            HIP_TRY(hipSetDevice(shards[r]->device));
-            bad = g_rccl.CommInitRank(&shards[r]->comm, n, uid, r);
+        hipError_t herr = hipSuccess; // (no early return between ncclGroupStart and ncclGroupEnd: an open group would swallow every later call of this thread)
+        for (int r = 0; r < n && !bad && herr == hipSuccess; ++r) {
+            herr = hipSetDevice(shards[r]->device);
+            if (herr == hipSuccess) bad = g_rccl.CommInitRank(&shards[r]->comm, n, uid, r);
         }
         const int end = g_rccl.GroupEnd();
-        if (bad || end) {
+        if (bad || end || herr != hipSuccess) {
             for (int r = 0; r < n; ++r) shards[r]->comm = nullptr; // (a communicator of a failed group is not one to destroy)
+            if (herr != hipSuccess) return fail(GYMRS_EHIP, std::string("gymrs_allreduce_stats_multi: hipSetDevice: ") + hipGetErrorString(herr));
             return nccl_fail("ncclCommInitRank (grouped, one rank per device)", bad ? bad : end);
         }
         for (int r = 0; r < n; ++r) {
@@ -513,11 +515,14 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
         if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
     if (int rc = g_rccl.GroupStart()) return nccl_fail("ncclGroupStart", rc);
     int bad = 0;
-    for (int r = 0; r < n && !bad; ++r) {
-        HIP_TRY(hipSetDevice(shards[r]->device));
-        bad = g_rccl.AllReduce(dev[(size_t)r], dev[(size_t)r], 4, 8 /* ncclFloat64 */, 0 /* ncclSum */, shards[r]->comm, shards[r]->stream);
+    hipError_t herr = hipSuccess;
+    for (int r = 0; r < n && !bad && herr == hipSuccess; ++r) {
+        herr = hipSetDevice(shards[r]->device);
+        if (herr == hipSuccess)
+            bad = g_rccl.AllReduce(dev[(size_t)r], dev[(size_t)r], 4, 8 /* ncclFloat64 */, 0 /* ncclSum */, shards[r]->comm, shards[r]->stream);
     }
     const int end = g_rccl.GroupEnd();
+    if (herr != hipSuccess) return fail(GYMRS_EHIP, std::string("gymrs_allreduce_stats_multi: hipSetDevice: ") + hipGetErrorString(herr));
     if (bad || end) return nccl_fail("ncclAllReduce (grouped)", bad ? bad : end);
     HIP_TRY(hipSetDevice(shards[0]->device));
     HIP_TRY(hipMemcpyAsync(out, dev[0], 4 * sizeof(double), hipMemcpyDeviceToHost, shards[0]->stream));
