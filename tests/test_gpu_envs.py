@@ -210,3 +210,20 @@ def test_reference_example_loops_run_through_the_mirrors():
     mc = load("mountain_car")
     total = mc.main(seed=3, verbose=False)
     assert 201 <= total <= 401  # the episode loop stops at done or after 201 steps; 200 more steps after close()
+    # the same loop for ONE batch cut into 3 blocks through the C ABI's native sharder (examples/sharded_cartpole.py): the batch's statistics = one engine's
+    sc = load("sharded_cartpole")
+    got = sc.main(lanes_per_gpu=1 << 15, blocks=3, steps=100, ring=4)
+    import importlib
+
+    import torch
+
+    gymrs = importlib.import_module("gym-rs_amd")
+    one = gymrs.BatchedEngine(gymrs.CARTPOLE, 3 << 15, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS)
+    one.reset(seed=0)
+    ring = torch.empty((4, 3 << 15), dtype=torch.uint8, device="cuda:0")
+    for b_ in range(4):
+        one.fill_actions(ring[b_].data_ptr(), seed=1, t=b_)
+    one.step_many(ring.data_ptr(), 3 << 15, 4, 100)
+    one.sync()
+    assert list(got) == list(one.stats()) and got[3] == (3 << 15) * 100 and got[2] > 0
+    one.close()
