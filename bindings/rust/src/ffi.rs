@@ -158,6 +158,8 @@ extern "C" {
         use_graph: c_int,
     ) -> c_int;
     pub fn gymrs_sharded_fill_actions(h: *mut GymrsSharded, actions_dev: *const *mut c_void, seed: u64, t: u64) -> c_int;
+    pub fn gymrs_sharded_rollout(h: *mut GymrsSharded, n_steps: u32, action_seed: u64, action_t0: u64) -> c_int;
+    pub fn gymrs_sharded_set_params(h: *mut GymrsSharded, params: *const c_void) -> c_int;
     pub fn gymrs_sharded_sync(h: *mut GymrsSharded) -> c_int;
     pub fn gymrs_sharded_stats(h: *mut GymrsSharded, out4: *mut f64) -> c_int;
     pub fn gymrs_sharded_stats_clear(h: *mut GymrsSharded) -> c_int;

@@ -107,6 +107,11 @@ impl ShardedEngine {
         check(ffi::gymrs_sharded_fill_actions(self.raw, actions_dev.as_ptr(), seed, t));
     }
 
+    /// `n_steps` random-policy steps of every lane fused into one launch per block (the loop of examples/cartpole.rs:15-30 per lane).
+    pub fn rollout(&mut self, n_steps: u32, action_seed: u64, action_t0: u64) {
+        check(unsafe { ffi::gymrs_sharded_rollout(self.raw, n_steps, action_seed, action_t0) });
+    }
+
     /// Wait for every block's stream; panics like the reference's `assert!` if a step saw an action outside the action space.
     pub fn sync(&mut self) {
         check(unsafe { ffi::gymrs_sharded_sync(self.raw) });

@@ -71,6 +71,8 @@ SIGNATURES = {
     "gymrs_sharded_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "gymrs_sharded_step_many": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int]),
     "gymrs_sharded_fill_actions": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint64]),
+    "gymrs_sharded_rollout": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint64]),
+    "gymrs_sharded_set_params": (C.c_int, [C.c_void_p, C.c_void_p]),
     "gymrs_sharded_sync": (C.c_int, [C.c_void_p]),
     "gymrs_sharded_stats": (C.c_int, [C.c_void_p, f64p]),
     "gymrs_sharded_stats_clear": (C.c_int, [C.c_void_p]),

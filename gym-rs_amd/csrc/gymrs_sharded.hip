@@ -263,6 +263,20 @@ gymrs_status gymrs_sharded_fill_actions(gymrs_sharded* h, void* const* actions_d
     });
 }
 
+// The fused random-policy rollout (gymrs_rollout) on every block: the action stream is keyed by GLOBAL lane ids, so the batch does what one engine would.
+gymrs_status gymrs_sharded_rollout(gymrs_sharded* h, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0)
+{
+    if (!h) return fail(GYMRS_EINVAL, "gymrs_sharded_rollout: handle is NULL");
+    return h->all([=](int) { return [=](gymrs_engine*& e) { return gymrs_rollout(e, n_steps, action_seed, action_t0); }; });
+}
+
+// `env.gravity = ...` for every lane of the batch (gymrs_set_params on every block).
+gymrs_status gymrs_sharded_set_params(gymrs_sharded* h, const void* params)
+{
+    if (!h || !params) return fail(GYMRS_EINVAL, "gymrs_sharded_set_params: NULL argument");
+    return h->all([=](int) { return [=](gymrs_engine*& e) { return gymrs_set_params(e, params); }; });
+}
+
 gymrs_status gymrs_sharded_sync(gymrs_sharded* h)
 {
     if (!h) return fail(GYMRS_EINVAL, "gymrs_sharded_sync: handle is NULL");

@@ -461,6 +461,17 @@ class ShardedEngine:
     def fill_actions(self, actions_dev: Sequence[int], seed: int, t: int) -> None:
         _check(self._lib, self._lib.gymrs_sharded_fill_actions(self._h, self._ptrs(actions_dev), int(seed), int(t)))
 
+    def rollout(self, n_steps: int, action_seed: int, action_t0: int = 0) -> None:
+        """``BatchedEngine.rollout`` on every block: ``n_steps`` random-policy steps fused into one launch per block."""
+        _check(self._lib, self._lib.gymrs_sharded_rollout(self._h, int(n_steps), int(action_seed), int(action_t0)))
+
+    def set_params(self, params) -> None:
+        """Assign the pub physics fields of every lane of the batch (``gymrs_set_params`` on every block)."""
+        if not isinstance(params, _PARAMS[self.kind]):
+            raise TypeError(f"expected {_PARAMS[self.kind].__name__}")
+        _check(self._lib, self._lib.gymrs_sharded_set_params(self._h, C.byref(params)))
+        self.params = type(params).from_buffer_copy(params)
+
     def sync(self) -> None:
         _check(self._lib, self._lib.gymrs_sharded_sync(self._h))
 

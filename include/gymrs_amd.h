@@ -289,6 +289,9 @@ gymrs_status gymrs_sharded_step(gymrs_sharded* h, const void* const* actions_dev
 gymrs_status gymrs_sharded_step_many(gymrs_sharded* h, const void* const* actions_dev, uint64_t stride_bytes,
                                      uint32_t n_buffers, uint32_t n_steps, int use_graph);
 gymrs_status gymrs_sharded_fill_actions(gymrs_sharded* h, void* const* actions_dev, uint64_t seed, uint64_t t);
+/* gymrs_rollout / gymrs_set_params on every block (the rollout's action stream is keyed by global lane ids: same bits as one engine). */
+gymrs_status gymrs_sharded_rollout(gymrs_sharded* h, uint32_t n_steps, uint64_t action_seed, uint64_t action_t0);
+gymrs_status gymrs_sharded_set_params(gymrs_sharded* h, const void* params);
 /* Waits for every block's stream; GYMRS_EACTION etc. as gymrs_sync (the first failing shard is reported). */
 gymrs_status gymrs_sharded_sync(gymrs_sharded* h);
 /* {sum_return, sum_length, n_episodes, n_steps} of the whole batch = gymrs_allreduce_stats_multi over the blocks. */

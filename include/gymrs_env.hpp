@@ -235,6 +235,8 @@ public:
     {
         check(gymrs_sharded_fill_actions(h_, actions_dev.data(), seed, t));
     }
+    void rollout(std::uint32_t n_steps, std::uint64_t action_seed, std::uint64_t action_t0 = 0) { check(gymrs_sharded_rollout(h_, n_steps, action_seed, action_t0)); }
+    void set_params(const void* params) { check(gymrs_sharded_set_params(h_, params)); }
     void sync() { check(gymrs_sharded_sync(h_)); }
     std::array<double, 4> stats() // {sum_return, sum_length, n_episodes, n_steps} of the whole batch
     {

@@ -105,6 +105,38 @@ def test_blocks_of_equal_size_step_many_and_invalid_actions(gymrs):
     one.close()
 
 
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_sharded_rollout_and_params_equal_one_engine(gymrs, kind):
+    """gymrs_sharded_rollout / gymrs_sharded_set_params: the fused rollout's action stream is keyed by global lane ids, the constants are uniform -- 5 blocks do
+    what one engine does, bit for bit (the loop of examples/cartpole.rs:15-30 for a batch over several GPUs)."""
+    n = 5 * 3072 + 77
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS | gymrs.TIME_LIMIT
+    sh = gymrs.ShardedEngine(kind, n, devices_for(5), flags=flags)
+    one = gymrs.BatchedEngine(kind, n, flags=flags, device=0)
+    p = gymrs.engine.default_params(kind)
+    if kind == 0:
+        p.force_mag = 12.5
+    elif kind == 1:
+        p.force = 0.0015
+    else:
+        p.g = 9.0
+    sh.set_params(p)
+    one.set_params(p)
+    sh.reset(seed=8)
+    one.reset(seed=8)
+    for t0 in (0, 130):
+        sh.rollout(130, action_seed=3, action_t0=t0)
+        one.rollout(130, action_seed=3, action_t0=t0)
+    sh.sync()
+    one.sync()
+    assert np.array_equal(sh.get_state().view(np.uint32), one.get_state().view(np.uint32))
+    got, want = sh.stats(), one.stats()
+    assert np.array_equal(got[1:], want[1:]) and got[3] == 260 * n and got[2] > 0
+    assert got[0] == want[0] if kind != 2 else got[0] == pytest.approx(want[0], rel=1e-12)
+    sh.close()
+    one.close()
+
+
 def test_allreduce_stats_multi_over_caller_made_engines(gymrs):
     """SURVEY 8b's form: the caller made the engines itself (global offsets by hand) and hands the array over."""
     lib = gymrs.load_library()
