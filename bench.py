@@ -1,36 +1,39 @@
 #!/usr/bin/env python
 """bench.py — env-steps/sec of the batched stepper (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts its own N ranks
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N > 1: starts its own N ranks (one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W      # or under an external launcher
+    python bench.py --in-process --gpus N ...                       # ONE process, the C ABI's native sharder (gymrs_sharded_*)
 
-A "step" is ONE Env::step() of every lane of the workload = one launch of the step kernel over the
-rank's shard (auto-reset and statistics on).  TWO call shapes are timed by the default run and both are printed (`paths`):
-  per_step_visible  the headline (`value`, `ms_per_step`, `roofline`): every step's arrays are RELEASED when its launch ends, so a
-                    reader between two steps -- the policy of examples/cartpole.rs:18-26, which looks at every step's ActionReward --
-                    sees them: K launches through HIP (what a gymrs_step loop enqueues; SURVEY H1 "keep the per-step round trip");
-  chain             reported separately: gymrs_step_many's chain through the engine's own dispatcher -- nothing is released until the
-                    chain ends, the state lives in the L2s in between (a multi-step-in-cache variant: SURVEY H1 "report separately").  Workload at N=1: BASELINE.json configs[1], CartPole-v1
-at 2^20 parallel envs, f32.  At N>1 every rank holds 2^20 lanes (weak scaling; configs[4] at N=8 is
-2^23 lanes) with global env ids rank*2^20+i and no data-path collective; the only collective of the
-path is one RCCL all-reduce of the 4 statistics doubles, taken AFTER the timed region (its cost is
-reported separately as stats_readout_us).
+What is printed: rank 0 writes ONE line to stdout, a digest of at most 4 KB (`compact_line`: the contract's fields, `config`, the headline's `roofline`,
+`cpu_baseline`, one small record per other call shape and BASELINE config -- names and numbers, no prose); the COMPLETE record (per-repetition times, per-rank
+records, notes, probes) goes to `bench_full.json` next to this script (`--full-out`) and, pretty-printed, to stderr; the line names the file (`full`).  Round 4
+printed the complete record as the line: 35 KB, of which the driver kept the last 8 KB and recorded `parsed: null`.
 
-Timing (">= 5 repetitions, report the median"): after W warm-up steps and ~60 ms of untimed stepping (the
-settle phase: a fresh process steps faster for its first ~20 ms than it does in the long run) the bench times R = 9
-repetitions and prints their min / median / max.  One repetition = P back-to-back passes of EXACTLY K steps, bracketed by
-barrier + torch.cuda.synchronize() on both sides (wall clock) and by HIP events on the engine's stream
-(kernel time); P is chosen once so that a repetition lasts >= ~5 ms -- K = 20 launches of a 7 us kernel
-are 0.14 ms, less than the host's own synchronisation jitter.  Per repetition the MAX over ranks is taken,
-then the MEDIAN over repetitions; ms_per_step = that time / (P * K), value = all lanes * P * K / that time.
-Nothing but the K-step passes sits inside a timed repetition.
+A "step" is ONE Env::step() of every lane of the workload = one launch of the step kernel over the rank's block (auto-reset and statistics on).  TWO call shapes
+are timed by the default run:
+  per_step_visible  the headline (`value`, `ms_per_step`, `roofline`): every step's arrays are RELEASED when its launch ends, so a reader between two steps -- the
+                    policy of examples/cartpole.rs:18-26, which looks at every step's ActionReward -- sees them: K launches through HIP (what a gymrs_step loop
+                    enqueues; SURVEY H1 "keep the per-step round trip").  `roofline.queue_launch_us`: the same shape once more through the engine's own queue
+                    with HIP's header on every packet (GYMRS_AQL=2), beside the HIP figure, never instead of it;
+  chain             reported separately: gymrs_step_many's chain through the engine's own dispatcher -- nothing is released until the chain ends, the state lives
+                    in the L2s in between (a multi-step-in-cache variant: SURVEY H1 "report separately").
+`roofline` (roofline_of): `frac` = bytes the kernel moves BY CONSTRUCTION / launch time / peak, `frac_moved` = device-wide counter bytes / time / 8 TB/s,
+`frac_counted` = the contract's algorithmic bytes (38 / 22 / 37 per env-step) -- the same three keys with the same meaning on every leg.
 
-Inputs are resident in HBM before the timed region: the state arrays, and a ring of pre-generated
-random-policy action buffers (the `rng.gen_range(0..=1)` of examples/cartpole.rs:19, produced on the
-device by the Philox action stream).
+Workload at N=1: BASELINE.json configs[1], CartPole-v1 at 2^20 parallel envs, f32.  At N>1 every rank holds 2^20 lanes (weak scaling; configs[4] at N=8 is 2^23
+lanes) with global env ids rank*2^20+i and no data-path collective; the only collective of the path is one RCCL all-reduce of the 4 statistics doubles, taken
+AFTER the timed region (its cost is reported separately as stats_readout_us).  `sharder` says which form ran: "single engine", "process-per-gpu", "in-process".
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how each field is obtained.
+Timing (">= 5 repetitions, report the median"): after W warm-up steps and ~60 ms of untimed stepping (the settle phase: a fresh process steps faster
+for its first ~20 ms than it does in the long run) the bench times R = 9 repetitions and reports their median (min / max in the full record).  One repetition =
+ONE gymrs_step_many call of P x K steps, bracketed by barrier + torch.cuda.synchronize() on both sides (wall clock) and by HIP events on the engine's stream
+(launch time); P is chosen once so that a repetition lasts >= 100 ms (MIN_REPETITION_SECONDS says why).  Per repetition the MAX over ranks is taken, then the
+MEDIAN over repetitions; ms_per_step = that time / (P * K), value = all lanes * P * K / that time.  Nothing but the K-step passes sits inside a timed repetition.
+
+Inputs are resident in HBM before the timed region: the state arrays, and a ring of pre-generated random-policy action buffers (the `rng.gen_range(0..=1)` of
+examples/cartpole.rs:19, produced on the device by the Philox action stream).  See DESIGN.md section 4.
 """
 from __future__ import annotations
 

@@ -47,6 +47,8 @@ AqlChain* aql_create(int hip_device, std::string* why);
 // discard: an error path (a failed hand-over, a tripped XCD check, a stream that could not be waited for) -- the queue is given back, not parked.
 void aql_destroy(AqlChain* c, bool discard = false);
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out);
+// the embedded stand-alone code object itself (developer experiment: the same binary launched through the HIP runtime's queue, gymrs_engine.hip)
+const void* aql_code_blob(size_t* bytes);
 
 // Largest kernel-argument block one dispatch may carry.
 constexpr size_t kAqlKernargSlot = 512;

@@ -663,6 +663,17 @@ void aql_destroy(AqlChain* c, bool discard)
     c->ctx->parked.push_back(c);
 }
 
+const void* aql_code_blob(size_t* bytes)
+{
+#if !defined(__HIP_DEVICE_COMPILE__)
+    *bytes = (size_t)(gymrs_aql_blob_end - gymrs_aql_blob_begin);
+    return gymrs_aql_blob_begin;
+#else
+    *bytes = 0;
+    return nullptr;
+#endif
+}
+
 bool aql_kernel(AqlChain* c, const char* name, AqlKernel* out)
 {
     std::lock_guard<std::mutex> lock(g_mu); // (engines of one device may ask from different threads: the in-process sharder's workers)

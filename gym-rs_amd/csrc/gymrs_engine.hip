@@ -1192,6 +1192,48 @@ static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const Ste
 }
 } // extern "C++"
 
+// Developer experiment (gymrs_dev_set_hooks bit 3; profiles/r05_visible_through_queue.log part 6): the CHAIN'S binary -- the kernel of the embedded stand-alone
+// code object -- launched through the HIP runtime's own queue (hipModuleLaunchKernel with the hand-filled kernel-argument block).  Same packet header as a
+// HIP launch of the library's own kernel, same queue; only the code object differs.  Tells "the binary" from "the queue" where the two submissions differ.
+extern "C++" {
+template <class Consts>
+static hipError_t module_launch(hipFunction_t f, int threads, const StepArgs& a, const Consts& c, hipStream_t stream)
+{
+    StepKernArgs<Consts> ka;
+    std::memset(&ka, 0, sizeof(ka));
+    ka.s0 = a.s[0];
+    ka.s1 = a.s[1];
+    ka.s2 = a.s[2];
+    ka.s3 = a.s[3];
+    ka.action = a.action;
+    ka.n_fast = a.n_fast;
+    ka.rest = a;
+    ka.c = c;
+    size_t bytes = sizeof(ka);
+    void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &ka, HIP_LAUNCH_PARAM_BUFFER_SIZE, &bytes, HIP_LAUNCH_PARAM_END};
+    return hipModuleLaunchKernel(f, step_grid(a.n, 4, threads * kStepTiles), 1, 1, (unsigned)threads, 1, 1, 0, stream, nullptr, extra);
+}
+} // extern "C++"
+
+static hipError_t launch_step_through_hip_module(gymrs_engine* e, uint32_t flags, const StepArgs& a)
+{
+    static hipModule_t mod[kMaxDevices] = {};
+    if (e->device < 0 || e->device >= kMaxDevices || e->vec != 4) return hipErrorInvalidValue;
+    if (!mod[e->device]) {
+        size_t bytes = 0;
+        const void* blob = aql_code_blob(&bytes);
+        if (hipError_t err = hipModuleLoadData(&mod[e->device], blob)) return err;
+    }
+    const int threads = step_threads_of(e->kind, e->n, e->vec);
+    hipFunction_t f = nullptr;
+    if (hipError_t err = hipModuleGetFunction(&f, mod[e->device], aql_kernel_name(e, flags, threads).c_str())) return err;
+    switch (e->kind) {
+    case GYMRS_CARTPOLE: return module_launch(f, threads, a, e->consts.cp, e->stream);
+    case GYMRS_MOUNTAIN_CAR: return module_launch(f, threads, a, e->consts.mc, e->stream);
+    default: return module_launch(f, threads, a, e->consts.pd, e->stream);
+    }
+}
+
 // steps [first, n_steps) of a gymrs_step_many call as ONE chain.  *taken = false: nothing was dispatched, use HIP launches.
 static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t stride_bytes, uint32_t n_buffers, uint32_t first, uint32_t n_steps,
                                   bool* taken)
@@ -1331,7 +1373,10 @@ gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t 
         if (gymrs_status st = flags_for_step(e, &flags)) return st;
         StepArgs a = step_args(e, base + (size_t)(t % n_buffers) * stride_bytes);
         if (gymrs_status st = log_before_step(e, flags, &a.fold_step)) return st;
-        HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
+        if (e->dev_hooks & 8u) // (developer experiment: the chain's binary through HIP's queue)
+            HIP_TRY(launch_step_through_hip_module(e, flags, a));
+        else
+            HIP_TRY(launch_step(e->kind, e->vec, flags, a, consts_ptr(e), e->stream));
         e->last_flags = flags;
         e->last_path = 1;
         e->tick += 1;

@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--all", type=int, default=0, help="print every repetition")
     ap.add_argument("--aql", default="", help="comma-separated GYMRS_AQL values (0 HIP launches, 1 chains, 2 the queue with HIP's header on every launch): "
                                               "one engine per (library, hint, value), timed alternately; default: the environment's")
+    ap.add_argument("--hooks", default="", help="comma-separated gymrs_dev_set_hooks bit sets (e.g. 0,8: 8 = the chain's binary through HIP's queue): one engine each")
     ap.add_argument("--nbuf", type=int, default=32, help="action buffers in the ring (32 = bench.py's default)")
     args = ap.parse_args()
     libs = [Lib(p) for p in (args.lib or [ROOT / "gym-rs_amd" / "libgymrs_amd.so"])]
@@ -71,7 +72,8 @@ def main():
     handles = []
     import os
 
-    aqls = [x for x in args.aql.split(",") if x] or [None]
+    hook_sets = [int(x) for x in args.hooks.split(",") if x] or [None]
+    aqls = [(q, hk) for q in ([x for x in args.aql.split(",") if x] or [None]) for hk in hook_sets]
     nts = [(int(x), q) for x in (args.nts.split(",") if args.nts else [str(args.nt)]) if x for q in aqls]
     libs = [lb for lb in libs for _ in nts]
     both = [m for _ in range(len(libs) // len(nts)) for m in nts]
@@ -79,8 +81,8 @@ def main():
     aql_of = [m[1] for m in both]
 
     def with_aql(q):
-        if q is not None:
-            os.environ["GYMRS_AQL"] = q
+        if q[0] is not None:
+            os.environ["GYMRS_AQL"] = q[0]
     for lb in libs:
         h = C.c_void_p()
         lb.ck(lb.lib.gymrs_engine_create(args.env, args.n, 0, 0, None, flags, C.byref(h)))
@@ -98,7 +100,11 @@ def main():
         s = C.c_void_p()
         lb.ck(lb.lib.gymrs_get_stream(h, C.byref(s)))
         engines.append((lb, h, torch.cuda.ExternalStream(s.value, device="cuda:0")))
-    keys = [f"{lb.path} nt={nt}" + (f" GYMRS_AQL={q}" if q is not None else "") for lb, nt, q in zip(libs, modes, aql_of)]
+    keys = [f"{lb.path} nt={nt}" + (f" GYMRS_AQL={q[0]}" if q[0] is not None else "") + (f" hooks={q[1]}" if q[1] is not None else "") for lb, nt, q in zip(libs, modes, aql_of)]
+    for (lb, h, _), q in zip(engines, aql_of):
+        if q[1] is not None:
+            lb.lib.gymrs_dev_set_hooks.argtypes = [C.c_void_p, C.c_uint32]
+            lb.ck(lb.lib.gymrs_dev_set_hooks(h, q[1]))
     times = {k: [] for k in keys}
     host = {k: [] for k in keys}
     for (lb, h, st), q in zip(engines, aql_of):  # warm-up (clocks, caches)
