@@ -46,6 +46,7 @@ def _needs_the_dispatcher(gymrs):
         with gymrs.BatchedEngine(0, 4096, flags=3) as eng:
             eng.reset(seed=1)
             ring = torch.zeros((2, 4096), dtype=torch.uint8, device="cuda:0")
+            torch.cuda.synchronize()  # (torch's fill runs on torch's stream, the engine reads on its own)
             eng.step_many(ring.data_ptr(), 4096, 2, 8)
             eng.sync()
             how = extras(eng)["aql"]

@@ -161,6 +161,7 @@ def test_action_buffers_of_any_alignment(gymrs, twin, kind):
     acts = [tw.fill_actions(3, b) for b in range(nbuf)]
     for b in range(nbuf):
         pool[off + b * n: off + (b + 1) * n] = torch.from_numpy(np.ascontiguousarray(acts[b])).to("cuda:0")
+    torch.cuda.synchronize()  # (the slice assignments are kernels on torch's stream; the engine reads on its own non-blocking stream)
     base = pool.data_ptr() + off * esz
     assert base % (4 * esz) != 0
     eng.step_many(base, n * esz, nbuf, steps)

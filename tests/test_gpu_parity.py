@@ -695,6 +695,7 @@ def test_mountain_car_reward_array_stays_right_around_invalid_actions(gymrs, twi
         assert (eng.get_step_result()[0] == -1.0).all()
     bad = torch.ones(n, dtype=torch.uint8, device="cuda:0")
     bad[1234] = 7
+    torch.cuda.synchronize()  # (torch wrote `bad` on its own stream)
     eng.step(bad.data_ptr())
     with pytest.raises(gymrs.InvalidActionError):
         eng.sync()
@@ -788,6 +789,7 @@ def test_cartpole_reward_array_stays_right_around_invalid_actions_when_elided(gy
         assert (eng.get_step_result()[0] == 1.0).all()
     bad = torch.ones(n, dtype=torch.uint8, device="cuda:0")
     bad[1234] = 7
+    torch.cuda.synchronize()  # (torch wrote `bad` on its own stream)
     eng.step(bad.data_ptr())
     with pytest.raises(gymrs.InvalidActionError):
         eng.sync()

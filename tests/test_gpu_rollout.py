@@ -171,6 +171,9 @@ def test_rollout_record_keeps_what_per_step_stepping_shows(gymrs, kind, flags):
     rew = torch.full((steps, stride), float("nan"), dtype=torch.float32, device=dev)
     done = torch.full((steps, stride), 9, dtype=torch.uint8, device=dev)
     trunc = torch.full((steps, stride), 9, dtype=torch.uint8, device=dev)
+    # torch filled these on ITS stream; the engine writes them on its own non-blocking stream: without this wait a fill can land after the rollout's first rows
+    # (found by round 5's suite soak, profiles/r05_suite_soak.log: 2 runs in 40 saw the fill value in the trailing lanes of row 0 / 1)
+    torch.cuda.synchronize()
     rec.rollout_record(steps, 3, t0, obs=obs.data_ptr(), actions=act.data_ptr(), reward=rew.data_ptr(), done=done.data_ptr(),
                        truncated=trunc.data_ptr(), lane_stride=stride)
     rec.sync()

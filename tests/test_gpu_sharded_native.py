@@ -26,6 +26,7 @@ def rings_for(sh, nbuf, esz, dtype):
     """One action ring per block ON THE BLOCK'S DEVICE, filled by the sharder (global lane ids -> the same actions as one engine's ring)."""
     pitch = max(s.n_envs for s in sh.shards)  # ONE row pitch for every block: gymrs_sharded_step_many takes one stride (the last block's rows are shorter)
     rings = [torch.zeros((nbuf, pitch), dtype=dtype, device=f"cuda:{s.device}") for s in sh.shards]
+    torch.cuda.synchronize()  # (torch's fills run on torch's stream, the engines write on their own)
     for b in range(nbuf):
         sh.fill_actions([r[b].data_ptr() for r in rings], seed=1, t=b)
     sh.sync()
@@ -54,6 +55,7 @@ def test_k_blocks_equal_one_engine(gymrs, kind, n, k):
     one.sync()
     cat = torch.cat([r[:, :s.n_envs].to("cuda:0") for r, s in zip(rings, sh.shards)], dim=1)
     assert torch.equal(cat, ring1)  # the blocks' rings ARE the unsharded ring: global lane ids in the Philox counters
+    torch.cuda.synchronize()
     # single steps (gymrs_sharded_step: one command per block per step), then one gymrs_sharded_step_many
     for t in range(7):
         sh.step([r[t % nbuf].data_ptr() for r in rings])
@@ -90,6 +92,7 @@ def test_blocks_of_equal_size_step_many_and_invalid_actions(gymrs):
     one.reset(seed=3)
     rings = rings_for(sh, nbuf, 1, torch.uint8)
     ring1 = torch.cat([r.to("cuda:0") for r in rings], dim=1).contiguous()
+    torch.cuda.synchronize()
     sh.step_many([r.data_ptr() for r in rings], 65536, nbuf, steps)
     one.step_many(ring1.data_ptr(), n, nbuf, steps)
     sh.sync()
@@ -97,6 +100,7 @@ def test_blocks_of_equal_size_step_many_and_invalid_actions(gymrs):
     assert np.array_equal(sh.get_state().view(np.uint32), one.get_state().view(np.uint32))
     assert np.array_equal(sh.stats(), one.stats()) and sh.stats()[2] > 0
     rings[2][0, 17] = 9  # not in Discrete(2)
+    torch.cuda.synchronize()
     sh.step([r[0].data_ptr() for r in rings])
     with pytest.raises(gymrs.InvalidActionError) as exc:
         sh.sync()

@@ -275,9 +275,12 @@ def test_small_engines_in_mapped_host_memory_match_large_ones(gymrs, kind):
     assert np.array_equal(small.stats()[1:], c_small.stats()[1:])
     if not (kind == 2):  # captured graphs on the mapped-memory engine (Pendulum with the time limit has no graph mode)
         ring = torch.zeros((8, 65), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()  # torch's stream and the engines' streams are not ordered against each other: wait on both sides of the hand-over
         for b in range(8):
             large.fill_actions(ring[b].data_ptr(), seed=6, t=b)
+        large.sync()
         small_ring = ring[:, :64].contiguous()
+        torch.cuda.synchronize()
         small.step_many(small_ring.data_ptr(), 64, 8, 80, use_graph=True)
         large.step_many(ring.data_ptr(), 65, 8, 80, use_graph=True)
         same(small, large)

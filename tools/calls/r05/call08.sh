@@ -87,3 +87,7 @@ for k in (1, 2, 4):
     print(f"gymrs_sharded_step, {k} block(s) on one GPU, one worker thread each: {e:6.2f} us per call enqueued, {w:6.2f} us per step incl. the final wait")
     sh.close()
 PY
+echo "# MountainCar / Pendulum: 8 lanes per work-item against 4 (HIP launches)" | tee -a gpurun_out/r05/cartpole_2p21.log
+for env in 1 2; do for vec in 4 8; do
+  timeout 600 python tools/step_timer.py --env $env --n $((env == 2 ? 1<<22 : 1<<20)) --steps 8000 --reps 5 --aql 0 --vec $vec --nbuf 8 2>&1 | grep "us median" | sed "s/^/env $env vec $vec: /" | tee -a gpurun_out/r05/cartpole_2p21.log
+done; done
