@@ -239,7 +239,9 @@ public:
         std::memcpy(slot, args, bytes);
         last_kernarg = slot;
         auto* p = &static_cast<hsa_kernel_dispatch_packet_t*>(q->base_address)[idx & (q->size - 1)];
-        const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        // (developer experiment GYMRS_AQL_EXP=16: a 3-dimensional dispatch like the HIP runtime's own packets, y = z = 1)
+        static const int exp_dims = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return (v && (std::atoi(v) & 16)) ? 3 : 1; }();
+        const uint16_t setup = (uint16_t)(exp_dims << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
         // the slot may still carry the header of the packet that used it a lap ago: no valid header over a half-written body
         __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)(HSA_PACKET_TYPE_INVALID << HSA_PACKET_HEADER_TYPE), __ATOMIC_RELAXED);
         p->workgroup_size_x = (uint16_t)wg;
