@@ -197,7 +197,6 @@ public:
     uint32_t calibrated_epoch = 0;
     bool forced_sync = false; // device-wide: the asynchronous hand-over does not work here at all (see aql_create)
     hsa_signal_t done{};
-    hsa_signal_t pace{}; // (developer experiment GYMRS_AQL_EXP=1: a completion signal on every releasing packet, as the HIP runtime attaches one)
     // 8 entries (one cache line each) the first step launch of every chain records {chain number, XCC} of its workgroups 0 .. 7 in and the
     // later launches of that chain compare against (StepArgs::xcc_table)
     uint32_t* xcc_table = nullptr;
@@ -239,9 +238,7 @@ public:
         std::memcpy(slot, args, bytes);
         last_kernarg = slot;
         auto* p = &static_cast<hsa_kernel_dispatch_packet_t*>(q->base_address)[idx & (q->size - 1)];
-        // (developer experiment GYMRS_AQL_EXP=16: a 3-dimensional dispatch like the HIP runtime's own packets, y = z = 1)
-        static const int exp_dims = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return (v && (std::atoi(v) & 16)) ? 3 : 1; }();
-        const uint16_t setup = (uint16_t)(exp_dims << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS);
+        const uint16_t setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         // the slot may still carry the header of the packet that used it a lap ago: no valid header over a half-written body
         __atomic_store_n(reinterpret_cast<uint32_t*>(p), (uint32_t)(HSA_PACKET_TYPE_INVALID << HSA_PACKET_HEADER_TYPE), __ATOMIC_RELAXED);
         p->workgroup_size_x = (uint16_t)wg;
@@ -333,11 +330,7 @@ bool load_code(DeviceCtx* c, std::string* why)
 bool make_queue(DeviceCtx* c, AqlChain* ch, std::string* why, std::atomic<int>* status = nullptr)
 {
     static const uint32_t queue_packets = [] { const char* v = std::getenv("GYMRS_AQL_QUEUE"); return v ? (uint32_t)std::strtoul(v, nullptr, 0) : kQueuePackets; }();
-    // (developer experiment GYMRS_AQL_EXP: 2 a MULTI-producer queue, 4 high priority, 8 profiling enabled on the queue -- what the HIP runtime's own queues have)
-    static const int exp_bits = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return v ? std::atoi(v) : 0; }();
-    HSA_OK(hsa_queue_create(c->gpu, queue_packets, (exp_bits & 2) ? HSA_QUEUE_TYPE_MULTI : HSA_QUEUE_TYPE_SINGLE, queue_error, status ? status : &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
-    if (exp_bits & 4) (void)hsa_amd_queue_set_priority(ch->q, HSA_AMD_QUEUE_PRIORITY_HIGH);
-    if (exp_bits & 8) (void)hsa_amd_profiling_set_profiler_enabled(ch->q, 1);
+    HSA_OK(hsa_queue_create(c->gpu, queue_packets, HSA_QUEUE_TYPE_SINGLE, queue_error, status ? status : &ch->queue_status, UINT32_MAX, UINT32_MAX, &ch->q), "hsa_queue_create");
     void* ka = nullptr;
     HSA_OK(hsa_amd_memory_pool_allocate(c->gpu_pool, (size_t)kKernargSlots * kAqlKernargSlot, 0, &ka), "kernel-argument ring");
     ch->kernarg = static_cast<char*>(ka);
@@ -637,7 +630,6 @@ static void aql_discard(AqlChain* c)
     if (c->ctx) c->ctx->live.fetch_sub(1, std::memory_order_relaxed);
     if (c->q) hsa_queue_destroy(c->q);
     if (c->done.handle) hsa_signal_destroy(c->done);
-    if (c->pace.handle) hsa_signal_destroy(c->pace);
     if (c->kernarg) hsa_amd_memory_pool_free(c->kernarg);
     if (c->xcc_table) (void)hipFree(c->xcc_table);
     if (c->in_flag) (void)hipFree(c->in_flag);
@@ -727,13 +719,9 @@ bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint
     static const int rel = [] { const char* v = std::getenv("GYMRS_AQL_FENCES"); return v && v[0] && v[1] >= '0' && v[1] <= '2' ? v[1] - '0' : (int)HSA_FENCE_SCOPE_NONE; }();
     // release = true: HIP's own header on this packet (agent-scope acquire AND release): what the launch wrote is written back when it ends -- the
     // per-step-visible shape submitted through this queue (gymrs_engine.hip, GYMRS_AQL=2)
-    static const int exp_bits = [] { const char* v = std::getenv("GYMRS_AQL_EXP"); return v ? std::atoi(v) : 0; }();
-    hsa_signal_t sig{0};
-    if (release && (exp_bits & 1)) {
-        if (!c->pace.handle && hsa_signal_create(1ll << 40, 0, nullptr, &c->pace) != HSA_STATUS_SUCCESS) c->pace.handle = 0;
-        sig = c->pace;
-    }
-    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, release ? (int)HSA_FENCE_SCOPE_AGENT : rel, sig, why);
+    // (round 5 tried, on this path, what the HIP runtime's own queues and packets have -- a completion signal per packet, a multi-producer / high-priority /
+    // profiled queue, 3-D dispatches: none moved a launch by more than 0.02 us; the experiment switch is gone again, profiles/r05_visible_through_queue.log)
+    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, release ? (int)HSA_FENCE_SCOPE_AGENT : rel, hsa_signal_t{0}, why);
 }
 
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
