@@ -470,7 +470,10 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
             distinct = distinct && shards[q]->device != shards[r]->device;
         }
     }
-    if (n == 1 || !distinct) { // host-side sum: same interface, no link to cross
+    // (test hook gymrs_dev_set_hooks bit 4 on shard 0: take the RCCL branch even for ONE shard -- a one-rank communicator made inside a group and a grouped
+    // all-reduce -- so that the grouped code path runs on a one-GPU test box at all: tests/test_gpu_sharded_native.py)
+    const bool force_rccl = n == 1 && (shards[0]->dev_hooks & 16u) != 0;
+    if ((n == 1 && !force_rccl) || !distinct) { // host-side sum: same interface, no link to cross
         double total[4] = {0, 0, 0, 0};
         std::vector<double*> dev((size_t)n);
         for (int r = 0; r < n; ++r) // every read-out kernel is enqueued before the first wait
@@ -793,9 +796,10 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* text, void*
     return GYMRS_OK;
 }
 
-// Test / developer hooks of the chain path (NOT in the header; tests/test_gpu_aql_chain.py and A/B tools bind it by name): bit 0 the next chains
-// find a poisoned XCD table (stands in for a workgroup deal that changed under the engine), bit 1 no XCD check (what it costs), bit 2 CartPole chains
-// with 256 work-items per workgroup.  Until round 4 these were environment variables read on every gymrs_step_many.
+// Test / developer hooks (NOT in the header; tests and A/B tools bind it by name): bit 0 the next chains find a poisoned XCD table (stands in for a
+// workgroup deal that changed under the engine), bit 1 no XCD check (what it costs), bit 2 CartPole chains with 256 work-items per workgroup, bit 3 HIP
+// launches of gymrs_step_many start the CHAIN'S binary (the embedded code object) through hipModuleLaunchKernel, bit 4 gymrs_allreduce_stats_multi takes
+// its grouped RCCL branch even for one shard.  Until round 4 these were environment variables read on every gymrs_step_many.
 gymrs_status gymrs_dev_set_hooks(gymrs_engine* e, uint32_t bits)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_dev_set_hooks: engine is NULL");

@@ -263,7 +263,8 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
  * thread holds every shard of a batch.  Shards on n DISTINCT devices: one RCCL communicator over exactly these engines (made on the first
  * call, all ranks inside one ncclGroupStart/End -- a bare gymrs_comm_init per engine from one thread would wait for the other ranks for
  * ever), then n grouped all-reduces of 32 bytes over xGMI, each on its engine's stream.  Shards sharing a device (RCCL refuses two ranks
- * on one GPU) or n = 1: the same four doubles are summed on the host.  *used_rccl (may be NULL) says which.  Synchronising. */
+ * on one GPU) or n = 1: the same four doubles are summed on the host.  *used_rccl (may be NULL) says which.  Synchronising; the calling thread's
+ * current HIP device is left on the last shard's. */
 gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl);
 
 /* A batch of n_total lanes cut into n_shards contiguous blocks, one engine per block on devices[r] (NULL = devices 0 .. n_shards-1; a

@@ -169,6 +169,41 @@ def test_allreduce_stats_multi_over_caller_made_engines(gymrs):
         e.close()
 
 
+def test_grouped_rccl_branch_runs_with_one_rank(gymrs):
+    """The grouped RCCL code of gymrs_allreduce_stats_multi (ncclGroupStart / ncclCommInitRank by value of the 128-byte id / ncclGroupEnd, then a grouped
+    ncclAllReduce of 4 f64 on the engine's stream) needs distinct devices, which a one-GPU box does not have -- so a test hook (gymrs_dev_set_hooks bit 4)
+    sends ONE shard through it: a one-rank communicator and a one-rank all-reduce.  Everything but the peer traffic is what an 8-GPU node executes.  Also
+    through the sharder (k = 1), twice (the communicator is made once and reused), and after a per-process gymrs_comm_init on the same engine (replaced)."""
+    lib = gymrs.load_library()
+    lib.gymrs_dev_set_hooks.argtypes = [C.c_void_p, C.c_uint32]
+    flags = gymrs.AUTO_RESET | gymrs.TRACK_STATS
+    eng = gymrs.BatchedEngine(gymrs.CARTPOLE, 50_000, flags=flags)
+    eng.reset(seed=2)
+    eng.rollout(200, action_seed=1)
+    want = eng.stats()
+    assert want[2] > 0
+    out, used = (C.c_double * 4)(), C.c_int(-1)
+    one = (C.c_void_p * 1)(eng._h)
+    assert lib.gymrs_allreduce_stats_multi(one, 1, out, C.byref(used)) == 0 and used.value == 0 and list(out) == list(want)  # default: host sum
+    assert lib.gymrs_dev_set_hooks(eng._h, 16) == 0
+    for _ in range(2):
+        out = (C.c_double * 4)()
+        assert lib.gymrs_allreduce_stats_multi(one, 1, out, C.byref(used)) == 0, lib.gymrs_last_error()
+        assert used.value == 1 and list(out) == list(want)
+    eng.comm_init(1, 0, eng.comm_unique_id())  # the per-process form on the same engine: replaces the grouped communicator ...
+    assert list(eng.allreduce_stats()) == list(want)
+    assert lib.gymrs_allreduce_stats_multi(one, 1, out, C.byref(used)) == 0 and used.value == 1 and list(out) == list(want)  # ... and back
+    eng.close()
+    sh = gymrs.ShardedEngine(gymrs.MOUNTAIN_CAR, 30_000, [0], flags=flags | gymrs.TIME_LIMIT)
+    sh.reset(seed=4)
+    sh.rollout(450, action_seed=2)
+    host = sh.stats()
+    assert sh.reduce_path == "host" and host[2] >= 30_000
+    assert lib.gymrs_dev_set_hooks(sh.shards[0]._h, 16) == 0
+    assert list(sh.stats()) == list(host) and sh.reduce_path == "rccl"
+    sh.close()
+
+
 def test_sharder_refuses_what_it_cannot_do(gymrs):
     lib = gymrs.load_library()
     h = C.c_void_p()
