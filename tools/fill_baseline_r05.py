@@ -49,7 +49,8 @@ def main():
         if first and name == "mountain_car_2p20":
             fc = first["configs"][name]
             val += (f" / {cf['launch_us']:.2f} us on this box; the round's first call, another box: {sci(fc['value'])} / {fc['launch_us']:.2f} us (these 4 us HIP launches go "
-                    f"host-bound on a slow launching thread; the queue's {f2(cf['roofline'].get('queue_launch_us'))} us does not)")
+                    f"host-bound on a slow launching thread -- 4.6-5.7 us on two other boxes of this round, `profiles/r05_visible_through_queue.log` -- the queue's "
+                    f"{f2(cf['roofline'].get('queue_launch_us'))} us does not)")
         rows.append(row(label, lanes, "per-step visible", val, cf["launch_us"], cf["roofline"]))
     rows.append("| 5 · CartPole, 2^23 lanes over 8 GPUs | 8 x 2^20 | both | driver-run: `bench.py --gpus 8` starts its own 8 ranks (`sharder: \"process-per-gpu\"`); "
                 "`bench.py --in-process --gpus 8` runs the C ABI's native sharder (one engine + one host thread per device, one grouped RCCL all-reduce): on this round's "
