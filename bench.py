@@ -593,6 +593,11 @@ def run_rank(args, info, backend, make_collective=None):
                                "submission": submission_of(path, t), "handover": t["handover"] if path == "chain" else None}
     hp = mine["paths"][head]  # the headline's figures also at the top of the rank record (what round 3's line carried)
     mine.update({"launch_us": hp["launch_us"], "launch_us_min": hp["launch_us_min"], "launch_us_max": hp["launch_us_max"], "submission": hp["submission"]})
+    if coll.active:  # this rank's OWN statistics beside the all-reduced ones: when a sharded total is ever off, the record says which block and by how much
+        try:
+            mine["episodes"] = [float(x) for x in eng.stats()]
+        except Exception as exc:  # noqa: BLE001 -- diagnostics only
+            mine["episodes"] = repr(exc)
     per_rank = coll.gather_to_root(mine)
     out = None
     if info.is_root:

@@ -65,7 +65,7 @@ def _native_backtrace_on_fatal_signals(tmp_path_factory):
     (tests/cpp/segv_trace.c), then let python's faulthandler have its say.  Round 4: one GPU suite run in ~50 died with a segmentation fault
     while a test was starting a subprocess (a fork from a process whose HIP runtime was up); since then the tests' children are forked by a helper
     that never loads the runtime (spawn_server.py).  Round 5's soak (profiles/r05_suite_soak.log: 101 runs of the suite's product-heavy part with
-    chains and with GYMRS_AQL=0, plus 8 full-suite runs) saw no crash under this handler; what it did find was a TEST race -- torch-initialised buffers
+    chains and with GYMRS_AQL=0, plus 30 full-suite runs) saw no crash under this handler; what it did find was a TEST race -- torch-initialised buffers
     handed to an engine's own non-blocking stream without waiting for torch's stream, 2 failures in 40 runs -- which is fixed."""
     import os
 

@@ -237,7 +237,9 @@ def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", str(8 * lanes), "--cpu-seconds", "0", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == eight["timing"]["passes_per_repetition"] == 2
     assert one["timing"]["calibration_passes"] == eight["timing"]["calibration_passes"]
-    assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0
+    # (the message carries every rank's own statistics: round 5's soak saw this comparison fail ONCE in 30 full-suite runs -- n_episodes + 1.4 %, sum_length + 0.002 % in
+    # the 8-process run -- and never in 170 stand-alone runs of the same command: profiles/r05_suite_soak.log part 3)
+    assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0, [(r["rank"], r.get("episodes"), r["paths"]["chain"]["submission"][:10], r["paths"]["chain"]["handover"]) for r in eight["ranks"]]
 
 
 @pytest.mark.parametrize("blocks", [1, 4])
