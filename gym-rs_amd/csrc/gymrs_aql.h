@@ -58,8 +58,9 @@ constexpr size_t kAqlKernargSlot = 512;
 bool aql_begin(AqlChain* c, hipStream_t stream, std::string* err);
 // grid_workitems = workgroups * workgroup_size.  Kernel arguments are copied.
 // release: the packet also carries an agent-scope RELEASE (HIP's own header) instead of the chain's acquire-only one.
+// system_acquire: the first launch behind aql_begin -- the acquire that FOLLOWS the hand-over (gymrs_aql.hip says why the opening packet's own is not enough).
 bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes,
-                  std::string* err, bool release = false);
+                  std::string* err, bool release = false, bool system_acquire = false);
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* err);
 // != 0 once a chain's first packet gave up waiting for the stream (checked by gymrs_sync); cleared by the call
 uint32_t aql_take_error(AqlChain* c);

@@ -710,7 +710,7 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
 }
 
 bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint32_t workgroup_size, const void* kernarg, size_t bytes, std::string* why,
-                  bool release)
+                  bool release, bool system_acquire)
 {
     // barrier bit: after the previous packet has completed.  Agent-scope ACQUIRE (L1 and scalar caches start clean: free,
     // measured), NO release: the lines this launch leaves dirty in an XCD's L2 are read by the next launch on that same XCD.
@@ -721,7 +721,13 @@ bool aql_dispatch(AqlChain* c, const AqlKernel& k, uint32_t grid_workitems, uint
     // per-step-visible shape submitted through this queue (gymrs_engine.hip, GYMRS_AQL=2)
     // (round 5 tried, on this path, what the HIP runtime's own queues and packets have -- a completion signal per packet, a multi-producer / high-priority /
     // profiled queue, 3-D dispatches: none moved a launch by more than 0.02 us; the experiment switch is gone again, profiles/r05_visible_through_queue.log)
-    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, acq, release ? (int)HSA_FENCE_SCOPE_AGENT : rel, hsa_signal_t{0}, why);
+    // system_acquire: the FIRST launch of a chain.  The chain's opening packet (the one-wave wait for the stream) carries a system-scope acquire too, but the packet
+    // processor performs a packet's acquire when it STARTS the packet -- i.e. possibly before the stream work the wait orders the chain against (a fold of the reset
+    // log, gymrs_stats_clear's memset, a copy) has run -- and the wait kernel's own fence only reaches the XCD it runs on.  An acquire has to FOLLOW the synchronisation:
+    // so the first launch behind the wait invalidates every L2 once more.  (Round 5's soak: one run in ~200 of 8 processes sharing a GPU kept, in one process, the
+    // episode counters an XCD's L2 still held from before gymrs_stats_clear -- profiles/r05_suite_soak.log part 3.)
+    return c->stage(k, grid_workitems, workgroup_size, kernarg, bytes, system_acquire ? (int)HSA_FENCE_SCOPE_SYSTEM : acq, release ? (int)HSA_FENCE_SCOPE_AGENT : rel,
+                    hsa_signal_t{0}, why);
 }
 
 bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)

@@ -1169,7 +1169,7 @@ static bool aql_usable(gymrs_engine* e, uint32_t n_steps)
 
 extern "C++" {
 template <class Consts>
-static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const StepArgs& a, const Consts& c, std::string* err, bool release)
+static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const StepArgs& a, const Consts& c, std::string* err, bool release, bool first)
 {
     StepKernArgs<Consts> ka;
     std::memset(&ka, 0, sizeof(ka));
@@ -1188,7 +1188,7 @@ static bool aql_step(gymrs_engine* e, const AqlKernel& k, int threads, const Ste
         *err = "kernel-argument segment of the chain kernel is " + std::to_string(k.kernarg_bytes) + " bytes, the dispatcher fills " + std::to_string(sizeof(ka));
         return false;
     }
-    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads * kStepTiles) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err, release);
+    return aql_dispatch(e->aql, k, step_grid(a.n, 4, threads * kStepTiles) * (uint32_t)threads, (uint32_t)threads, &ka, sizeof(ka), err, release, first);
 }
 } // extern "C++"
 
@@ -1293,13 +1293,14 @@ static gymrs_status step_many_aql(gymrs_engine* e, const char* base, uint64_t st
         a.xcc_table = aql_xcc_table(e->aql);
         a.xcc_check = (e->chain_first && !poisoned) ? 2u : 1u;
         a.xcc_seq = aql_chain_number(e->aql);
+        const bool first_of_chain = e->chain_first; // its packet carries the acquire that follows the hand-over (aql_dispatch)
         e->chain_first = false;
         if (no_xcc_check || visible) a.xcc_check = 0u;
         bool ok = false;
         switch (e->kind) {
-        case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err, visible); break;
-        case GYMRS_MOUNTAIN_CAR: ok = aql_step(e, k, threads, a, e->consts.mc, &err, visible); break;
-        case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err, visible); break;
+        case GYMRS_CARTPOLE: ok = aql_step(e, k, threads, a, e->consts.cp, &err, visible, first_of_chain); break;
+        case GYMRS_MOUNTAIN_CAR: ok = aql_step(e, k, threads, a, e->consts.mc, &err, visible, first_of_chain); break;
+        case GYMRS_PENDULUM: ok = aql_step(e, k, threads, a, e->consts.pd, &err, visible, first_of_chain); break;
         }
         if (!ok) return bail(fail(GYMRS_EHIP, "AQL dispatcher: " + err));
         e->last_flags = flags;

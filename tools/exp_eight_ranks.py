@@ -23,6 +23,7 @@ try:
     else:
         key = "chain" if sys.argv[1] == "both" else sys.argv[1]
         subs = sorted({str(r["paths"][key]["submission"])[:12] + "/" + str(r["paths"][key]["handover"])[:12] for r in full["ranks"]})
-        print(f"WRONG sum_length {ep['sum_length']:.0f} n_episodes {ep['n_episodes']:.0f} (want {WANT[0]:.0f} {WANT[1]:.0f}); submissions {subs}")
+        per_rank = [(r["rank"], r.get("episodes")) for r in full["ranks"]]
+        print(f"WRONG sum_length {ep['sum_length']:.0f} n_episodes {ep['n_episodes']:.0f} (want {WANT[0]:.0f} {WANT[1]:.0f}); submissions {subs}; per rank {per_rank}")
 except Exception as exc:  # noqa: BLE001
     print("FAILED", res.returncode, repr(exc), res.stderr[-300:].replace("\n", " | "))
