@@ -179,6 +179,33 @@ def moved_bytes(env_name: str, engine_extras: dict) -> float:
     return MOVED_BYTES[env_name] - (4.0 if (env_name == "cartpole" and engine_extras.get("reward_store_elided")) else 0.0)
 
 
+def cgroup_cpu_quota(root: str = "/sys/fs/cgroup"):
+    """CPUs' worth of time the container's cgroup grants per period (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us); None = unlimited / unknown."""
+    try:
+        quota, period = (Path(root) / "cpu.max").read_text().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float((Path(root) / "cpu" / "cpu.cfs_quota_us").read_text())
+        period = float((Path(root) / "cpu" / "cpu.cfs_period_us").read_text())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
+def usable_cpus(root: str = "/sys/fs/cgroup"):
+    """(threads the CPU baseline's multi-thread leg runs, where that number came from)."""
+    try:
+        mask = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        mask = os.cpu_count() or 1
+    quota = cgroup_cpu_quota(root)
+    if quota is not None and quota < mask:
+        return max(1, int(quota)), f"cgroup CPU quota {quota:g} (affinity mask {mask}, host {os.cpu_count()})"
+    return max(1, mask), f"affinity mask {mask} CPUs, no smaller cgroup quota (host {os.cpu_count()})"
+
+
 def cpu_baseline(kind: int, target_seconds: float):
     """The reference's single-env caller loop in the f64 C oracle, one host thread (kind "port":
     the reference is a Rust crate and cannot be built in this image)."""
@@ -193,9 +220,10 @@ def cpu_baseline(kind: int, target_seconds: float):
     # loop runs without the GIL).  Reported beside the single-thread value, never instead of it.
     import threading
 
-    # 16 threads at most: the GPU boxes report 256 logical CPUs but a container CPU quota of far fewer
-    # (256 threads measured only 9x the single-thread rate), and the sample has to stay short.
-    cores = min(os.cpu_count() or 1, 16)
+    # As many threads as this process may really run at once ("all host cores, labelled as such" -- not a constant): the CPUs of
+    # its affinity mask, capped by the container's cgroup CPU quota where there is one (the GPU boxes report 256 logical CPUs; 256 threads
+    # under a quota of a few CPUs measured only 9x the single-thread rate).  The line says where the number came from.
+    cores, cores_from = usable_cpus()
     per_thread = max(int(rate * min(target_seconds, 2.0)), 1_000_000)
     times = [0.0] * cores
 
@@ -215,7 +243,7 @@ def cpu_baseline(kind: int, target_seconds: float):
         "cores": 1,
         "multi_thread": {"value": cores * per_thread / all_wall, "cores": cores,
                          "sample": f"{cores} independent single-env loops (threads) x {per_thread} steps, {all_wall:.1f} s wall, "
-                                   f"host reports {os.cpu_count()} logical CPUs"},
+                                   f"host reports {os.cpu_count()} logical CPUs; threads = {cores_from}"},
         "kind": "port",
         "sample": f"{n} consecutive Env::step() calls of ONE env (f64 C restatement of gym-rs step()+reset, "
                   f"random actions, reset on done; loop shape of examples/cartpole.rs:15-30, RenderMode::None), "

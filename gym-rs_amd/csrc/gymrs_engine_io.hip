@@ -448,8 +448,7 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4])
     // ncclFloat64 = 8, ncclSum = 0 (rccl.h); 32 bytes per rank: latency-bound, rides the engine stream
     if (int rc = g_rccl.AllReduce(dev, dev, 4, 8, 0, e->comm, e->stream)) return nccl_fail("ncclAllReduce", rc);
     HIP_TRY(hipMemcpyAsync(out, dev, 4 * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return GYMRS_OK;
+    return stream_sync_checked(e); // (like every synchronising read-out: a tripped chain fails THIS call)
 }
 
 // The in-process form (`gymrs_allreduce_stats(gymrs_engine** shards, int n, double out[4])`): ONE host thread holds every shard of a
@@ -458,6 +457,14 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4])
 // for ever), and every later call issues the n all-reduces of 32 bytes inside one group, each on its engine's stream.  Where two shards share
 // a device RCCL refuses the communicator ("duplicate GPU"), and nothing has to cross a link: the same four doubles are summed on the host.
 // Either way every engine's statistics read-out runs on its own stream first and `out` holds the batch's totals when the call returns.
+// stream_sync_checked with the shard named in the message: a read-out over several engines must say WHICH one a tripped chain belongs to
+static gymrs_status sync_shard_checked(gymrs_engine* e, int index)
+{
+    const gymrs_status st = stream_sync_checked(e);
+    if (st == GYMRS_OK) return st;
+    return fail(st, "shard " + std::to_string(index) + " (device " + std::to_string(e->device) + "): " + gymrs_last_error());
+}
+
 gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl)
 {
     if (!shards || n < 1 || !out) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats_multi: NULL argument or n < 1");
@@ -480,8 +487,7 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
             if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
         for (int r = 0; r < n; ++r) {
             HIP_TRY(hipSetDevice(shards[r]->device));
-            HIP_TRY(hipStreamSynchronize(shards[r]->stream));
-            std::atomic_thread_fence(std::memory_order_acquire);
+            if (gymrs_status st = sync_shard_checked(shards[r], r)) return st;
             for (int j = 0; j < 4; ++j) total[j] += shards[r]->stats_host[j];
         }
         for (int j = 0; j < 4; ++j) out[j] = total[j];
@@ -529,10 +535,18 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
     if (bad || end) return nccl_fail("ncclAllReduce (grouped)", bad ? bad : end);
     HIP_TRY(hipSetDevice(shards[0]->device));
     HIP_TRY(hipMemcpyAsync(out, dev[0], 4 * sizeof(double), hipMemcpyDeviceToHost, shards[0]->stream));
-    for (int r = 0; r < n; ++r) { // every rank's copy of the sum is complete when the call returns
+    gymrs_status first_bad = GYMRS_OK;
+    std::string first_msg;
+    for (int r = 0; r < n; ++r) { // every rank's copy of the sum is complete when the call returns (every stream is waited for, the FIRST failure is reported)
         HIP_TRY(hipSetDevice(shards[r]->device));
-        HIP_TRY(hipStreamSynchronize(shards[r]->stream));
+        if (gymrs_status st = sync_shard_checked(shards[r], r)) {
+            if (first_bad == GYMRS_OK) {
+                first_bad = st;
+                first_msg = gymrs_last_error();
+            }
+        }
     }
+    if (first_bad != GYMRS_OK) return fail(first_bad, first_msg);
     if (used_rccl) *used_rccl = 1;
     return GYMRS_OK;
 }
@@ -804,6 +818,41 @@ gymrs_status gymrs_dev_set_hooks(gymrs_engine* e, uint32_t bits)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_dev_set_hooks: engine is NULL");
     e->dev_hooks = bits;
+    return GYMRS_OK;
+}
+
+// Developer hook (NOT in the header; tools/coldstart_amp.py binds it by name): the RAW bookkeeping arrays as device memory holds them, without the
+// fold a statistics call or a snapshot would run first -- the post-mortem of a wrong episode count wants to see WHICH per-wavefront slots, which lanes'
+// start ticks and which rows of the reset log differ from a clean engine's.  what: 0 the per-wavefront slots {episodes, return bits} (16 B each), 1 ep_start
+// (4 B per lane), 2 the reset log (8 rows of log_row_words u64), 3 {n_stat_blocks, log_row_words, log_pending, log_first_tick lo / hi, tick lo / hi, epoch} as
+// u32.  Waits for the engine's stream (plainly), then copies at most `bytes`; *copied = the array's size.
+gymrs_status gymrs_dev_peek(gymrs_engine* e, int what, void* host_out, uint64_t bytes, uint64_t* copied)
+{
+    if (!e || !host_out) return fail(GYMRS_EINVAL, "gymrs_dev_peek: NULL argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const void* src = nullptr;
+    uint64_t size = 0;
+    uint32_t info[8] = {e->n_stat_blocks, e->log_row_words, e->log_pending, (uint32_t)e->log_first_tick, (uint32_t)(e->log_first_tick >> 32),
+                        (uint32_t)e->tick, (uint32_t)(e->tick >> 32), e->epoch};
+    switch (what) {
+    case 0: src = e->block_stats; size = (uint64_t)e->n_stat_blocks * 16; break;
+    case 1: src = e->ep_start; size = e->n * 4; break;
+    case 2: src = e->reset_log; size = e->reset_log ? (uint64_t)kResetLogRows * e->log_row_words * 8 : 0; break;
+    case 3:
+        if (copied) *copied = sizeof(info);
+        std::memcpy(host_out, info, bytes < sizeof(info) ? bytes : sizeof(info));
+        return GYMRS_OK;
+    default: return fail(GYMRS_EINVAL, "gymrs_dev_peek: unknown array");
+    }
+    if (copied) *copied = size;
+    const uint64_t take = bytes < size ? bytes : size;
+    if (take && src) {
+        if (e->pool_host && what == 1)
+            std::memcpy(host_out, host_of(e, e->ep_start), take);
+        else
+            HIP_TRY(hipMemcpy(host_out, src, take, hipMemcpyDeviceToHost));
+    }
     return GYMRS_OK;
 }
 

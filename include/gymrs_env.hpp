@@ -197,6 +197,9 @@ public:
         : n_(n_total), state_dim_(kind == GYMRS_CARTPOLE ? 4 : 2)
     {
         check(gymrs_sharded_create(kind, n_total, global_env_offset, (int)devices.size(), devices.data(), params, flags, &h_));
+        int k = 0;
+        check(gymrs_sharded_count(h_, &k));
+        n_blocks_ = (std::size_t)k;
     }
     ~ShardedVecEnv() { gymrs_sharded_destroy(h_); }
     ShardedVecEnv(const ShardedVecEnv&) = delete;
@@ -226,13 +229,20 @@ public:
         return used;
     }
     // actions_dev[r]: block r's actions (ring) on ITS device
-    void step_device(const std::vector<const void*>& actions_dev) { check(gymrs_sharded_step(h_, actions_dev.data())); } // async
+    // (the native side reads actions_dev[r] for EVERY block: a shorter vector would be an out-of-bounds read that ends as a wild device pointer)
+    void step_device(const std::vector<const void*>& actions_dev) // async
+    {
+        one_pointer_per_block(actions_dev.size(), "step_device");
+        check(gymrs_sharded_step(h_, actions_dev.data()));
+    }
     void step_many(const std::vector<const void*>& actions_dev, std::uint64_t stride_bytes, std::uint32_t n_buffers, std::uint32_t n_steps)
     {
+        one_pointer_per_block(actions_dev.size(), "step_many");
         check(gymrs_sharded_step_many(h_, actions_dev.data(), stride_bytes, n_buffers, n_steps, 0));
     }
     void fill_actions(const std::vector<void*>& actions_dev, std::uint64_t seed, std::uint64_t t)
     {
+        one_pointer_per_block(actions_dev.size(), "fill_actions");
         check(gymrs_sharded_fill_actions(h_, actions_dev.data(), seed, t));
     }
     void rollout(std::uint32_t n_steps, std::uint64_t action_seed, std::uint64_t action_t0 = 0) { check(gymrs_sharded_rollout(h_, n_steps, action_seed, action_t0)); }
@@ -259,8 +269,14 @@ public:
     std::uint64_t size() const { return n_; }
 
 private:
+    void one_pointer_per_block(std::size_t given, const char* who) const
+    {
+        if (given != n_blocks_)
+            throw std::invalid_argument(std::string("ShardedVecEnv::") + who + ": " + std::to_string(given) + " action pointers for " + std::to_string(n_blocks_) + " blocks");
+    }
     std::uint64_t n_;
     int state_dim_;
+    std::size_t n_blocks_ = 0;
     gymrs_sharded* h_ = nullptr;
 };
 

@@ -18,22 +18,25 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "oversubscribed: starts several processes that share the one GPU of the test box (runs after every single-process correctness test)")
     config.addinivalue_line("markers", "perf: asserts a RATE or a timing relation (still runs under -m gpu, but after every correctness test)")
 
 
-# The order of a `-m gpu -x` run (VERDICT r3 "next" #6): parity against the oracle first, the machinery (twin / chain / fuzz) next, the
-# bench contract after that, and every test that asserts a rate or a timing relation (`perf` marker) LAST -- one noisy box must not
-# stop the run before the parity rows have been tested.
+# The order of a `-m gpu -x` run (VERDICT r3 "next" #6, r5 "next" #3): parity against the oracle first, the machinery (twin / chain / fuzz) next, the
+# in-process native sharder after that, then the bench contract -- and inside the non-perf block every test that starts SEVERAL processes on the one GPU
+# (`oversubscribed` marker: a test mode, the likeliest to flake) LAST, so that a subprocess flake cannot hide product tests (round 5: one such failure cut
+# off 23 tests, among them all of test_gpu_sharded_native).  Tests that assert a rate or a timing relation (`perf` marker) come after everything else.
 GPU_ORDER = ["test_gpu_parity", "test_gpu_slowpaths", "test_gpu_envs", "test_gpu_pcg64_reset", "test_gpu_params_and_serde",
-             "test_gpu_reset_log", "test_gpu_time_limit_elision", "test_gpu_rollout", "test_gpu_aql_chain", "test_gpu_fuzz",
-             "test_gpu_bench_contract"]
+             "test_gpu_reset_log", "test_gpu_time_limit_elision", "test_gpu_rollout", "test_gpu_stats_readout", "test_gpu_aql_chain", "test_gpu_fuzz",
+             "test_gpu_sharded_native", "test_gpu_bench_contract", "test_gpu_handover"]
 
 
 def _order_key(indexed):
     index, item = indexed
     module = Path(str(item.fspath)).stem
     rank = GPU_ORDER.index(module) if module in GPU_ORDER else len(GPU_ORDER)
-    return (1 if item.get_closest_marker("perf") is not None else 0, rank, index)
+    block = 2 if item.get_closest_marker("perf") is not None else (1 if item.get_closest_marker("oversubscribed") is not None else 0)
+    return (block, rank, index)
 
 
 def pytest_collection_modifyitems(config, items):

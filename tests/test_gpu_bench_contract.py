@@ -200,6 +200,7 @@ def test_plain_form_spawns_its_own_ranks():
     assert d["config"]["total_lanes"] == n << 20
 
 
+@pytest.mark.oversubscribed
 def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     """The N>1 code path on a 1-GPU box (TEST mode --oversubscribe: both ranks on cuda:0, gloo between them): two shards
     of n lanes with global offsets 0 and n must produce exactly the statistics of ONE engine with 2n lanes run through the
@@ -215,6 +216,7 @@ def test_two_ranks_share_the_gpu_and_equal_one_engine_of_twice_the_lanes():
     assert one["episodes"] == two["episodes"] and one["episodes"]["n_episodes"] > 0
 
 
+@pytest.mark.oversubscribed
 @pytest.mark.parametrize("lanes", [32768, 1 << 20])
 def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     """BASELINE configs[4]'s SHAPE on a 1-GPU box (VERDICT r2 "next" #1e; lanes = 2^20: its exact size, 2^23 lanes with global env ids
