@@ -66,6 +66,7 @@ __global__ __launch_bounds__(kBlock) void fill_actions_kernel(typename Env::Acti
 //   L = sum over lanes of (ep_start - epoch) = total length of the episodes finished since the last reset()
 //       (episodes tile a lane's time axis, so the start tick of the open episode is all a lane has to keep),
 //   E = finished episodes, R = sum of returns (Pendulum only; for the constant-reward envs return = +-length).
+// Read-only towards everything a step kernel touches: rows of the reset log that are not folded yet are counted where they lie (see_through_log).
 // Two launches, no atomics, no memset: stats_partial_kernel streams ep_start (one dwordx4 per work-item per pass) and
 // the per-wavefront slots, reduces inside the wavefront with shuffles, across the 16 wavefronts of a workgroup
 // through 384 bytes of LDS, and writes ONE {L, E, R} triple per workgroup; stats_finalize_kernel (one workgroup)
@@ -117,28 +118,69 @@ __device__ __forceinline__ void block_sum3(unsigned long long& len, unsigned lon
     }
 }
 
+// The reset log's pending rows as the read-out sees them (StatsArgs::log): passed by value, wave-uniform.
+struct PendingLog {
+    const unsigned long long* log;
+    uint32_t row_words, pending;
+    uint64_t first_tick;
+    uint32_t vec;
+};
+
+// Lanes l0 .. l0 + count - 1 (l0 a multiple of 4, count <= 4; all in one work-item's group of the launches that wrote the rows): start ticks as a fold
+// of the pending rows WOULD leave them -- the most recent re-arm of a lane wins -- and, for the group that holds bit 0 of its words, the number of bits
+// (= finished episodes) of those words over all pending rows.  Read-only.
+__device__ __forceinline__ void see_through_log(const PendingLog& lg, uint64_t l0, uint32_t count, uint32_t* ep4, unsigned long long& episodes)
+{
+    const uint64_t lanes_per_wave = 64ull * lg.vec;
+    const uint64_t wave = l0 / lanes_per_wave;
+    const uint32_t within = (uint32_t)(l0 % lanes_per_wave), bit = within / lg.vec, k0 = within % lg.vec;
+    const uint64_t word0 = wave * lg.vec + k0;
+    if (word0 + count > lg.row_words) return; // (cannot happen: the ring has a word for every group of the batch)
+    uint32_t seen = 0;
+    for (uint32_t i = 0; i < lg.pending; ++i) { // newest first
+        const uint64_t t = lg.first_tick + lg.pending - 1 - i;
+        const unsigned long long* row = lg.log + (size_t)((uint32_t)t & (kResetLogRows - 1u)) * lg.row_words + word0;
+        for (uint32_t j = 0; j < count; ++j) {
+            const unsigned long long w = row[j];
+            if (bit == 0) episodes += (unsigned long long)__popcll(w);
+            if (((w >> bit) & 1ull) && !((seen >> j) & 1u)) {
+                seen |= 1u << j;
+                ep4[j] = (uint32_t)(t + 1); // the next episode started at the next tick
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kStatsThreads) void stats_partial_kernel(const uint32_t* __restrict__ ep_start, uint64_t n, uint32_t epoch,
                                                                       const unsigned long long* __restrict__ bs, uint32_t n_slots,
-                                                                      unsigned long long* __restrict__ partials)
+                                                                      unsigned long long* __restrict__ partials, const PendingLog lg)
 {
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     unsigned long long len = 0, ep = 0;
     double ret = 0.0;
     const uint64_t tid = (uint64_t)blockIdx.x * kStatsThreads + threadIdx.x, stride = (uint64_t)gridDim.x * kStatsThreads;
     const uint64_t n4 = n >> 2; // ep_start is 256-byte aligned (engine_create)
     const u4* v = reinterpret_cast<const u4*>(ep_start);
+    const bool through = lg.pending != 0; // wave-uniform
     for (uint64_t i = tid; i < n4; i += stride) {
         const u4 x = v[i]; // plain, not non-temporal: see above
+        uint32_t e4[4] = {x.x, x.y, x.z, x.w};
+        if (through) see_through_log(lg, i << 2, 4u, e4, ep);
         // each difference is taken in 32 bits (ticks wrap), the sum in 64
-        len += (unsigned long long)(uint32_t)(x.x - epoch) + (uint32_t)(x.y - epoch) + (uint32_t)(x.z - epoch) + (uint32_t)(x.w - epoch);
+        len += (unsigned long long)(uint32_t)(e4[0] - epoch) + (uint32_t)(e4[1] - epoch) + (uint32_t)(e4[2] - epoch) + (uint32_t)(e4[3] - epoch);
     }
-    for (uint64_t i = (n4 << 2) + tid; i < n; i += stride) len += (uint32_t)(ep_start[i] - epoch);
-    const ull2* slots = reinterpret_cast<const ull2*>(bs);
+    if ((n & 3u) != 0 && tid == 0) { // the ragged last group of up to three lanes
+        uint32_t e4[4] = {0, 0, 0, 0};
+        const uint32_t count = (uint32_t)(n & 3u);
+        for (uint32_t j = 0; j < count; ++j) e4[j] = ep_start[(n4 << 2) + j];
+        if (through) see_through_log(lg, n4 << 2, count, e4, ep);
+        for (uint32_t j = 0; j < count; ++j) len += (uint32_t)(e4[j] - epoch);
+    }
+    // The per-wavefront slots are read AROUND the caches (system-scope loads): each slot has one writer -- its wavefront, in the stream's launches or in a chain
+    // on the engine's own queue -- and this kernel may run on any XCD.
     for (uint64_t b = tid; b < n_slots; b += stride) {
-        const ull2 s = slots[b];
-        ep += s.x;
-        ret += __builtin_bit_cast(double, (unsigned long long)s.y);
+        ep += __hip_atomic_load(bs + b * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ret += __builtin_bit_cast(double, __hip_atomic_load(bs + b * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
     block_sum3<kStatsThreads / 64>(len, ep, ret);
     if (threadIdx.x == 0) {
@@ -222,8 +264,8 @@ hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_re
     return hipGetLastError();
 }
 
-// mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps}; mode 1: remember L as the new base
-// (statistics cleared); mode 2: base = 0 (after reset(); n_partials = 0).
+// mode 0: out4 = {sum_return, sum_length, n_episodes, n_steps} since the baseline; mode 1: the totals now become the baseline
+// (statistics cleared); mode 2: baseline = 0 (after reset(), which zeroed the counters itself; n_partials = 0).
 __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const unsigned long long* __restrict__ partials, uint32_t n_partials,
                                                                          unsigned long long* base, int mode, int reward_sign, double n_steps,
                                                                          double* out4, volatile double* host_out4)
@@ -240,14 +282,17 @@ __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const u
     if (threadIdx.x != 0) return;
     if (mode == 1) {
         base[0] = len;
+        base[1] = ep;
+        base[2] = __builtin_bit_cast(unsigned long long, ret);
         return;
     }
     if (mode == 2) {
-        base[0] = 0;
+        base[0] = base[1] = 0;
+        base[2] = __builtin_bit_cast(unsigned long long, 0.0);
         return;
     }
     const double flen = (double)(len - base[0]);
-    const double r[4] = {reward_sign != 0 ? reward_sign * flen : ret, flen, (double)ep, n_steps};
+    const double r[4] = {reward_sign != 0 ? reward_sign * flen : ret - __builtin_bit_cast(double, base[2]), flen, (double)(ep - base[1]), n_steps};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         out4[j] = r[j];
@@ -263,8 +308,9 @@ hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
         const uint64_t items = (a.n >> 2) > a.n_blocks ? (a.n >> 2) : a.n_blocks;
         const uint64_t want = (items + kStatsThreads - 1) / kStatsThreads;
         grid = (uint32_t)(want < 1 ? 1 : (want > (uint64_t)kStatsMaxBlocks ? (uint64_t)kStatsMaxBlocks : want));
+        const PendingLog lg{a.log, a.log_row_words, a.log ? a.log_pending : 0u, a.log_first_tick, (uint32_t)(a.log_vec > 0 ? a.log_vec : 4)};
         hipLaunchKernelGGL(stats_partial_kernel, dim3(grid), dim3(kStatsThreads), 0, stream, a.ep_start, a.n, a.epoch, a.block_stats,
-                           a.n_blocks, a.partials);
+                           a.n_blocks, a.partials, lg);
     }
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(1), dim3(kStatsMaxBlocks), 0, stream, a.partials, grid, a.base, mode, a.reward_sign,
                        a.n_steps, a.out4, a.host_out4);

@@ -166,7 +166,7 @@ struct SnapshotHeader {
 };
 static_assert(sizeof(CartPoleConsts) <= 96 && sizeof(MountainCarConsts) <= 96 && sizeof(PendulumConsts) <= 96, "consts blob too small");
 static_assert(sizeof(gymrs_cartpole_params) <= 96 && sizeof(gymrs_mountain_car_params) <= 96 && sizeof(gymrs_pendulum_params) <= 96, "params blob too small");
-constexpr uint32_t kSnapshotVersion = 3;
+constexpr uint32_t kSnapshotVersion = 4; // 4: the statistics baseline is {L, E, R} (round 6), not L alone
 
 struct Segment {
     void* dev;
@@ -187,7 +187,7 @@ std::vector<Segment> snapshot_segments(const gymrs_engine* e)
     v.push_back({e->ep_start, n * 4});
     v.push_back({e->block_stats, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long)});
     v.push_back({e->wave_open, (size_t)e->n_stat_blocks * sizeof(double)});
-    v.push_back({e->stats_base, sizeof(unsigned long long)});
+    v.push_back({e->stats_base, (size_t)kStatsBaseWords * sizeof(unsigned long long)});
     v.push_back({e->err, 2 * sizeof(uint32_t)});
     return v;
 }
@@ -357,7 +357,7 @@ gymrs_status gymrs_stats_device(gymrs_engine* e, double** dev_out4)
 {
     if (!e || !dev_out4) return fail(GYMRS_EINVAL, "gymrs_stats_device: NULL argument");
     HIP_TRY(hipSetDevice(e->device));
-    if (gymrs_status st = fold_reset_log(e)) return st;
+    // (no fold: the read-out looks through the reset log's pending rows and writes nothing a step kernel reads -- launch_stats, gymrs_kernels.h)
     HIP_TRY(launch_stats(stats_args(e), 0, e->stream));
     *dev_out4 = e->stats_dev;
     return GYMRS_OK;
@@ -378,8 +378,8 @@ gymrs_status gymrs_stats_clear(gymrs_engine* e)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_stats_clear: engine is NULL");
     HIP_TRY(hipSetDevice(e->device));
-    if (gymrs_status st = fold_reset_log(e)) return st;
-    HIP_TRY(hipMemsetAsync(e->block_stats, 0, (size_t)e->n_stat_blocks * 2 * sizeof(unsigned long long), e->stream));
+    // Baseline, not zeroing (round 6): one read-only pass remembers {sum of start ticks, finished episodes, sum of returns} as they are NOW -- pending rows
+    // of the reset log included -- and every later read-out subtracts them.  Nothing the step kernels read is written from the stream.
     HIP_TRY(launch_stats(stats_args(e), 1, e->stream));
     e->n_steps_total = 0;
     return GYMRS_OK;

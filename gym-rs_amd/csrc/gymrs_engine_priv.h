@@ -115,7 +115,7 @@ struct gymrs_engine {
     volatile double* stats_host = nullptr; // mapped host memory the read-out kernel writes the same four doubles into
     double* stats_host_dev = nullptr;      // the device's address of it
     unsigned long long* stats_acc = nullptr;  // [kStatsPartials][3] scratch of the statistics read-out
-    unsigned long long* stats_base = nullptr; // [1] length sum at the last gymrs_stats_clear
+    unsigned long long* stats_base = nullptr; // [kStatsBaseWords] the statistics BASELINE {sum of start ticks, episodes, returns} of the last gymrs_stats_clear
     uint32_t epoch = 1;                       // ep_start value written by the last reset()
     void* action_staging = nullptr; // for gymrs_step_host
     uint64_t seed = 0, tick = 0;

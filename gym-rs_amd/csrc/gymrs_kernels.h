@@ -185,14 +185,25 @@ struct StatsArgs {
     const unsigned long long* block_stats;
     uint32_t n_blocks;
     unsigned long long* partials; // [kStatsPartials][3] scratch: one {L, E, R} triple per workgroup of the read-out
-    unsigned long long* base; // [1] L at the last stats_clear
+    unsigned long long* base; // [kStatsBaseWords] {L, E, R (f64 bits)} at the last stats_clear: the BASELINE a read-out subtracts (see launch_stats)
+    // the reset log's rows that are not folded yet: the read-out looks THROUGH them (read-only) instead of folding them first
+    const unsigned long long* log;
+    uint32_t log_row_words, log_pending;
+    uint64_t log_first_tick;
+    int log_vec;
     int track;                // GYMRS_TRACK_STATS set
     int reward_sign;          // +1 CartPole, -1 MountainCar (return = +-length), 0 Pendulum (summed)
     double n_steps;
     double* out4;             // {sum_return, sum_length, n_episodes, n_steps}
     double* host_out4;        // the same four into device-visible host memory (or NULL): a read-out without the copy engine
 };
-// mode 0 read, 1 clear (base = L), 2 after reset (base = 0)
+// mode 0 read, 1 clear (base = the totals now), 2 after reset (base = 0).
+// The read-out WRITES NOTHING a step kernel reads (round 6; VERDICT r5 "next" #1c): gymrs_stats_clear used to zero the per-wavefront counters with a
+// memset on the stream and to fold the reset log with an atomic-add kernel -- stream-side writes into memory the next launches (of the stream or of a chain on
+// the engine's own queue) read-modify-write, the one place where round 5's stale episode counter could come from.  Now the counters only ever grow, written by
+// the one wavefront that owns each slot; a clear remembers the totals and a read subtracts them (u64: exact; Pendulum's f64 return sum: to an ulp of the
+// total), and rows of the reset log that are still pending are counted where they lie.
+constexpr int kStatsBaseWords = 4;
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream);
 // The age of the oldest open episode, max over lanes of (uint32_t)(tick_ref - ep_start[lane]), from which the host derives
 // the tick before which no lane's episode started (GYMRS_TIME_LIMIT elision, gymrs_engine.hip).  partials = kStatsPartials
