@@ -465,6 +465,22 @@ static gymrs_status sync_shard_checked(gymrs_engine* e, int index)
     return fail(st, "shard " + std::to_string(index) + " (device " + std::to_string(e->device) + "): " + gymrs_last_error());
 }
 
+// every engine's read-out on its own stream, the four doubles summed on the host
+static gymrs_status host_sum_stats(gymrs_engine** shards, int n, double out[4])
+{
+    double total[4] = {0, 0, 0, 0};
+    std::vector<double*> dev((size_t)n);
+    for (int r = 0; r < n; ++r) // every read-out kernel is enqueued before the first wait
+        if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
+    for (int r = 0; r < n; ++r) {
+        HIP_TRY(hipSetDevice(shards[r]->device));
+        if (gymrs_status st = sync_shard_checked(shards[r], r)) return st;
+        for (int j = 0; j < 4; ++j) total[j] += shards[r]->stats_host[j];
+    }
+    for (int j = 0; j < 4; ++j) out[j] = total[j];
+    return GYMRS_OK;
+}
+
 gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl)
 {
     if (!shards || n < 1 || !out) return fail(GYMRS_EINVAL, "gymrs_allreduce_stats_multi: NULL argument or n < 1");
@@ -480,28 +496,28 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
     // (test hook gymrs_dev_set_hooks bit 4 on shard 0: take the RCCL branch even for ONE shard -- a one-rank communicator made inside a group and a grouped
     // all-reduce -- so that the grouped code path runs on a one-GPU test box at all: tests/test_gpu_sharded_native.py)
     const bool force_rccl = n == 1 && (shards[0]->dev_hooks & 16u) != 0;
-    if ((n == 1 && !force_rccl) || !distinct) { // host-side sum: same interface, no link to cross
-        double total[4] = {0, 0, 0, 0};
-        std::vector<double*> dev((size_t)n);
-        for (int r = 0; r < n; ++r) // every read-out kernel is enqueued before the first wait
-            if (gymrs_status st = gymrs_stats_device(shards[r], &dev[(size_t)r])) return st;
-        for (int r = 0; r < n; ++r) {
-            HIP_TRY(hipSetDevice(shards[r]->device));
-            if (gymrs_status st = sync_shard_checked(shards[r], r)) return st;
-            for (int j = 0; j < 4; ++j) total[j] += shards[r]->stats_host[j];
-        }
-        for (int j = 0; j < 4; ++j) out[j] = total[j];
+    if ((n == 1 && !force_rccl) || !distinct) return host_sum_stats(shards, n, out); // host-side sum: same interface, no link to cross
+    // First contact with RCCL must not cost the caller its result (VERDICT r5 "next" #4: a first run on 8 devices should be boring): when the library
+    // cannot be loaded or the grouped communicator cannot be made -- BEFORE any collective has been enqueued anywhere -- the same four doubles are summed on
+    // the host, *used_rccl = -1 says so and gymrs_last_error() keeps RCCL's own message.  A failure of an all-reduce that was already enqueued is an error.
+    auto fall_back = [&](gymrs_status why) -> gymrs_status {
+        const std::string msg = gymrs_last_error();
+        (void)why;
+        if (gymrs_status st = host_sum_stats(shards, n, out)) return st;
+        if (used_rccl) *used_rccl = -1;
+        (void)fail(GYMRS_OK, "RCCL unavailable, statistics summed on the host: " + msg);
         return GYMRS_OK;
-    }
-    if (gymrs_status st = rccl_load()) return st;
-    if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fail(GYMRS_ENCCL, "librccl lacks ncclGroupStart / ncclGroupEnd");
+    };
+    if ((shards[0]->dev_hooks & 32u) != 0) return fall_back(fail(GYMRS_ENCCL, "test hook: RCCL treated as unavailable")); // (tests: the fall-back itself)
+    if (gymrs_status st = rccl_load()) return fall_back(st);
+    if (!g_rccl.GroupStart || !g_rccl.GroupEnd) return fall_back(fail(GYMRS_ENCCL, "librccl lacks ncclGroupStart / ncclGroupEnd"));
     bool have = true;
     for (int r = 0; r < n; ++r) have = have && shards[r]->comm && shards[r]->n_ranks == n && shards[r]->comm_rank == r;
     if (!have) { // first call for this set of shards (or another set before): one communicator over exactly these engines, rank = index
         for (int r = 0; r < n; ++r) comm_destroy(shards[r]);
         NcclId128 uid;
-        if (int rc = g_rccl.GetUniqueId(&uid)) return nccl_fail("ncclGetUniqueId", rc);
-        if (int rc = g_rccl.GroupStart()) return nccl_fail("ncclGroupStart", rc);
+        if (int rc = g_rccl.GetUniqueId(&uid)) return fall_back(nccl_fail("ncclGetUniqueId", rc));
+        if (int rc = g_rccl.GroupStart()) return fall_back(nccl_fail("ncclGroupStart", rc));
         int bad = 0;
         hipError_t herr = hipSuccess; // (no early return between ncclGroupStart and ncclGroupEnd: an open group would swallow every later call of this thread)
         for (int r = 0; r < n && !bad && herr == hipSuccess; ++r) {
@@ -512,7 +528,7 @@ gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double ou
         if (bad || end || herr != hipSuccess) {
             for (int r = 0; r < n; ++r) shards[r]->comm = nullptr; // (a communicator of a failed group is not one to destroy)
             if (herr != hipSuccess) return fail(GYMRS_EHIP, std::string("gymrs_allreduce_stats_multi: hipSetDevice: ") + hipGetErrorString(herr));
-            return nccl_fail("ncclCommInitRank (grouped, one rank per device)", bad ? bad : end);
+            return fall_back(nccl_fail("ncclCommInitRank (grouped, one rank per device)", bad ? bad : end));
         }
         for (int r = 0; r < n; ++r) {
             shards[r]->n_ranks = n;
@@ -813,7 +829,7 @@ gymrs_status gymrs_params_from_json(gymrs_env_kind kind, const char* text, void*
 // Test / developer hooks (NOT in the header; tests and A/B tools bind it by name): bit 0 the next chains find a poisoned XCD table (stands in for a
 // workgroup deal that changed under the engine), bit 1 no XCD check (what it costs), bit 2 CartPole chains with 256 work-items per workgroup, bit 3 HIP
 // launches of gymrs_step_many start the CHAIN'S binary (the embedded code object) through hipModuleLaunchKernel, bit 4 gymrs_allreduce_stats_multi takes
-// its grouped RCCL branch even for one shard.  Until round 4 these were environment variables read on every gymrs_step_many.
+// its grouped RCCL branch even for one shard, bit 5 that branch treats RCCL as unavailable (the host-sum fall-back of a failed first contact).  Until round 4 these were environment variables read on every gymrs_step_many.
 gymrs_status gymrs_dev_set_hooks(gymrs_engine* e, uint32_t bits)
 {
     if (!e) return fail(GYMRS_EINVAL, "gymrs_dev_set_hooks: engine is NULL");

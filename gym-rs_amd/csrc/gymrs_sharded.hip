@@ -239,7 +239,7 @@ struct gymrs_sharded {
     uint32_t flags = 0;
     std::vector<Worker*> w;
     std::vector<gymrs_engine*> engines;
-    int last_used_rccl = -1; // -1: no statistics call yet
+    int last_used_rccl = -2; // -2: no statistics call yet; 1 RCCL, 0 host-side sum, -1 host-side sum because RCCL was unavailable
     std::string reduce_path;
 
     // every worker runs its job concurrently; the first failure (lowest shard) is reported on the CALLER's thread
@@ -472,6 +472,7 @@ gymrs_status gymrs_sharded_stats(gymrs_sharded* h, double out[4])
     int used = 0;
     if (gymrs_status st = gymrs_allreduce_stats_multi(h->engines.data(), (int)h->engines.size(), out, &used)) return st;
     h->last_used_rccl = used;
+    h->reduce_path = used > 0 ? "rccl" : (used == 0 ? "host" : std::string("host (") + gymrs_last_error() + ")");
     return GYMRS_OK;
 }
 
@@ -517,8 +518,8 @@ gymrs_status gymrs_sharded_get_step_result(gymrs_sharded* h, uint64_t first, uin
 // shard), or "none" before the first call.
 const char* gymrs_sharded_reduce_path(gymrs_sharded* h)
 {
-    if (!h || h->last_used_rccl < 0) return "none";
-    return h->last_used_rccl ? "rccl" : "host";
+    if (!h || h->last_used_rccl == -2) return "none";
+    return h->reduce_path.c_str();
 }
 
 } // extern "C"

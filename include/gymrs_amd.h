@@ -176,7 +176,10 @@ gymrs_status gymrs_step_host(gymrs_engine* e, const void* actions_host);
  * actions_dev + (t % n_buffers) * stride_bytes.  use_graph != 0 replays a captured HIP graph of >= 32 steps
  * (a whole number of passes over the action ring; the remainder is launched eagerly): worth it when the step
  * kernel is shorter than a host launch (~3 us, i.e. small batches); results are identical.  Not available
- * for Pendulum with GYMRS_TIME_LIMIT (GYMRS_EINVAL). */
+ * for Pendulum with GYMRS_TIME_LIMIT (GYMRS_EINVAL).
+ * Submission (round 6): HIP launches on the engine's stream -- every step's arrays are released when its launch ends, exactly what a loop of
+ * gymrs_step enqueues.  GYMRS_AQL=1 in the environment OPTS IN to chains on the engine's own HSA queue (release only at the end of the call,
+ * 25 % less per launch; one process per GPU: INTEGRATION.md "gymrs_step_many"); results are the same bits either way. */
 gymrs_status gymrs_step_many(gymrs_engine* e, const void* actions_dev, uint64_t stride_bytes,
                              uint32_t n_buffers, uint32_t n_steps, int use_graph);
 /* Fused random-policy rollout: exactly the effect of
@@ -245,7 +248,9 @@ gymrs_status gymrs_get_step_result(gymrs_engine* e, uint64_t first, uint64_t cou
                                    uint8_t* done, uint8_t* truncated /* each may be NULL */);
 
 /* ---- episode statistics (the all-reduce payload) --------------------------------------------- */
-/* out = {sum_return, sum_length, n_episodes, n_steps} for this engine's lanes (synchronising). */
+/* out = {sum_return, sum_length, n_episodes, n_steps} for this engine's lanes since the last gymrs_stats_clear / gymrs_reset (synchronising).
+ * The read-out writes nothing a step reads (round 6): gymrs_stats_clear remembers the totals as a baseline that later read-outs subtract (integers:
+ * exact; Pendulum's sum_return: a difference of two f64 sums) -- asynchronous on the engine's stream, no counter is zeroed. */
 gymrs_status gymrs_stats(gymrs_engine* e, double out[4]);
 gymrs_status gymrs_stats_clear(gymrs_engine* e);
 /* Reduce the per-workgroup partials into 4 doubles in device memory (async on the engine's stream)
@@ -263,13 +268,17 @@ gymrs_status gymrs_allreduce_stats(gymrs_engine* e, double out[4]);
  * thread holds every shard of a batch.  Shards on n DISTINCT devices: one RCCL communicator over exactly these engines (made on the first
  * call, all ranks inside one ncclGroupStart/End -- a bare gymrs_comm_init per engine from one thread would wait for the other ranks for
  * ever), then n grouped all-reduces of 32 bytes over xGMI, each on its engine's stream.  Shards sharing a device (RCCL refuses two ranks
- * on one GPU) or n = 1: the same four doubles are summed on the host.  *used_rccl (may be NULL) says which.  Synchronising; the calling thread's
- * current HIP device is left on the last shard's. */
+ * on one GPU) or n = 1: the same four doubles are summed on the host.  *used_rccl (may be NULL) says which: 1 RCCL, 0 the host-side sum, -1 the
+ * host-side sum BECAUSE RCCL could not be loaded or its communicator could not be made (round 6: first contact with RCCL does not cost the caller
+ * its result; gymrs_last_error() then holds RCCL's message although the status is GYMRS_OK).  Synchronising; the calling thread's current HIP device
+ * is left on the last shard's. */
 gymrs_status gymrs_allreduce_stats_multi(gymrs_engine** shards, int n, double out[4], int* used_rccl);
 
 /* A batch of n_total lanes cut into n_shards contiguous blocks, one engine per block on devices[r] (NULL = devices 0 .. n_shards-1; a
  * device may appear more than once), lane i of the batch carrying the global id global_env_offset + i whatever the cut -- so every result
- * below is bit-identical to ONE engine of n_total lanes.  Each engine is driven by its own host thread, bound to its device, for its
+ * below is bit-identical to ONE engine of n_total lanes (one exception: Pendulum's sum_return is a float sum over wavefront slots, and k engines
+ * add their slots in another order than one -- equal to ~1e-12 relative; every integer statistic, every state bit, every reward / flag is identical).
+ * Blocks are whole 1024-lane tiles dealt evenly (the first `tiles % n_shards` blocks hold one more), the ragged tail in the last.  Each engine is driven by its own host thread, bound to its device, for its
  * whole life: the calls below hand one command to every thread and return when all have ENQUEUED (the step calls stay asynchronous on
  * each engine's stream).  One gymrs_sharded is driven by one caller thread at a time (`&mut self`, core.rs:42-50).
  * Creation seeds every block with ONE OS-entropy seed (cartpole.rs:92,120).  Error messages name the shard and its device. */
@@ -298,7 +307,7 @@ gymrs_status gymrs_sharded_sync(gymrs_sharded* h);
 /* {sum_return, sum_length, n_episodes, n_steps} of the whole batch = gymrs_allreduce_stats_multi over the blocks. */
 gymrs_status gymrs_sharded_stats(gymrs_sharded* h, double out[4]);
 gymrs_status gymrs_sharded_stats_clear(gymrs_sharded* h);
-/* "rccl" | "host" | "none": how the last gymrs_sharded_stats summed. */
+/* "rccl" | "host" | "host (RCCL unavailable, ...: <RCCL's message>)" | "none": how the last gymrs_sharded_stats summed. */
 const char* gymrs_sharded_reduce_path(gymrs_sharded* h);
 /* Host copies over lanes [first, first + count) of the BATCH, laid out exactly as gymrs_get_state / gymrs_get_step_result lay out an
  * engine's lanes (SoA: state_dim arrays of `count` floats back to back).  Synchronising. */

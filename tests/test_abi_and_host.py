@@ -407,3 +407,23 @@ def test_every_environment_variable_the_library_reads_is_documented():
     assert "GYMRS_AQL" in read
     doc = (ROOT / "INTEGRATION.md").read_text()
     assert not [v for v in sorted(read) if v not in doc]
+
+
+def test_cpu_baseline_threads_follow_the_cgroup_quota(tmp_path):
+    """the multi-thread leg of cpu_baseline uses the CPUs this process may really run on -- its affinity mask, capped by the container's
+    cgroup CPU quota (v2 cpu.max, v1 cfs quota / period) -- and says which, instead of a constant."""
+    import bench
+
+    (tmp_path / "cpu.max").write_text("350000 100000\n")
+    assert bench.cgroup_cpu_quota(str(tmp_path)) == 3.5
+    n, how = bench.usable_cpus(str(tmp_path))
+    assert n == min(3, len(os.sched_getaffinity(0))) and ("cgroup CPU quota 3.5" in how or "affinity mask" in how)
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cgroup_cpu_quota(str(tmp_path)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("200000\n")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cgroup_cpu_quota(str(v1)) == 2.0
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.cgroup_cpu_quota(str(v1)) is None and bench.usable_cpus(str(v1))[0] == len(os.sched_getaffinity(0))

@@ -224,7 +224,9 @@ def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     ranks itself, each a shard with global env ids rank * n + i on cuda:0, gloo between them (RCCL refuses 8 ranks on one
     device).  The line carries 8 rank records, the roofline object and (short sample) the CPU baseline; the statistics equal
     ONE engine of 8n lanes run through the same schedule."""
-    common = ["--steps", "30", "--warmup", "10", "--no-probe", "--repetitions", "5", "--action-buffers", "8"]
+    # The product's DEFAULT submission (HIP launches: `--path per_step_visible`).  The opt-in chains under processes sharing a GPU are tests/test_gpu_handover.py's
+    # subject: thousands of hand-overs per run, every iteration against the twin -- the 56 chain calls this command used to add tested them far less.
+    common = ["--steps", "30", "--warmup", "10", "--no-probe", "--repetitions", "5", "--action-buffers", "8", "--path", "per_step_visible"]
     env = dict(os.environ, GYMRS_BENCH_PASSES="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
     eight = run([sys.executable, "bench.py", "--gpus", "8", "--oversubscribe", "--n-envs", str(lanes), "--cpu-seconds", "1", *common], env=env)
     check_common(eight, 8, 30, 10, min_ms=0.0, min_frac=0.0)  # (8 small shards taking turns on one GPU: not a rate)
@@ -233,15 +235,18 @@ def test_eight_ranks_share_the_gpu(tmp_path, lanes):
     assert eight["cpu_baseline"]["kind"] == "port" and eight["cpu_baseline"]["value"] > 1e6  # an N > 1 line carries it too
     assert eight["roofline"]["bound"] == "hbm" and eight["config"]["comm_watchdog"] == "not triggered"
     # every rank says how it submits each call shape, and the line says whether they agree (VERDICT r3 "next" #8)
-    assert eight["ranks_agree"] in (True, False) and all(set(r["paths"]) == {"per_step_visible", "chain"} for r in eight["ranks"])
-    assert eight["ranks_agree"] == (len({(r["paths"]["chain"]["submission"], (r["paths"]["chain"]["handover"] or "").split(" (")[0]) for r in eight["ranks"]}) == 1)
+    assert eight["ranks_agree"] is True and all(set(r["paths"]) == {"per_step_visible"} for r in eight["ranks"])
     assert eight["expected_job_rate_from_rank_launch_times"] > 0
     one = run([sys.executable, "bench.py", "--gpus", "1", "--n-envs", str(8 * lanes), "--cpu-seconds", "0", *common], env=env)
     assert one["timing"]["passes_per_repetition"] == eight["timing"]["passes_per_repetition"] == 2
     assert one["timing"]["calibration_passes"] == eight["timing"]["calibration_passes"]
     # (the message carries every rank's own statistics: round 5's soak saw this comparison fail ONCE in 30 full-suite runs -- n_episodes + 1.4 %, sum_length + 0.002 % in
     # the 8-process run -- and never in 170 stand-alone runs of the same command: profiles/r05_suite_soak.log part 3)
-    assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0, [(r["rank"], r.get("episodes"), r["paths"]["chain"]["submission"][:10], r["paths"]["chain"]["handover"]) for r in eight["ranks"]]
+    # every rank's own statistics on stdout (pytest shows it with a failure; an assertion message is cut): a wrong count names its block
+    for r in eight["ranks"]:
+        print("rank", r["rank"], r.get("episodes"), {k: v["submission"][:12] for k, v in r["paths"].items()})
+    print("eight", eight["episodes"], "one", one["episodes"])
+    assert one["episodes"] == eight["episodes"] and one["episodes"]["n_episodes"] > 0
 
 
 @pytest.mark.parametrize("blocks", [1, 4])

@@ -43,10 +43,10 @@ def schedule(mode, calls_per_shape):
     return [(mode, CALL)] * (2 * calls_per_shape)
 
 
-def expected_stats(twin_mod, gymrs, rank, lanes, seed, n_post_calls):
-    """The twin's statistics for one iteration of (rank, seed): [before the clear, after the run]."""
+def expected_stats(twin_mod, gymrs, rank, lanes, seed, n_post_calls, flags=3, audit=False):
+    """The twin's statistics for one iteration of (rank, seed): [after the warm-up, before the clear, after the run (, state, step results)]."""
     tw, TwinEngine = twin_mod
-    e = TwinEngine(tw, 0, lanes, gymrs.engine.default_params(0), flags=3, gid0=rank * lanes)
+    e = TwinEngine(tw, 0, lanes, gymrs.engine.default_params(0), flags=flags, gid0=rank * lanes)
     e.reset(seed)
     ring = [e.fill_actions(1, b) for b in range(NBUF)]
     mid = None
@@ -60,6 +60,8 @@ def expected_stats(twin_mod, gymrs, rank, lanes, seed, n_post_calls):
     for _ in range(n_post_calls):
         for t in range(CALL):
             e.step(ring[t % NBUF])
+    if audit:
+        return mid, pre, e.stats().copy(), e.get_state().copy(), tuple(a.copy() for a in e.get_result())
     return mid, pre, e.stats().copy()
 
 
@@ -72,7 +74,7 @@ def worker(args):
     rank, lanes = args.rank, args.lanes
     post = schedule(args.mode, args.calls)
     t0 = time.time()
-    want = {s: expected_stats((Twin(), TwinEngine), gymrs, rank, lanes, s, len(post)) for s in range(args.seeds)}
+    want = {s: expected_stats((Twin(), TwinEngine), gymrs, rank, lanes, s, len(post), args.flags, args.audit) for s in range(args.seeds)}
     t_twin = time.time() - t0
     shm = shared_memory.SharedMemory(name=args.shm) if args.shm else None
     slots = np.ndarray((args.procs,), dtype=np.int64, buffer=shm.buf) if shm else None
@@ -86,7 +88,12 @@ def worker(args):
 
     torch.cuda.set_device(0)
     os.environ.pop("GYMRS_AQL", None)
-    eng = gymrs.BatchedEngine(0, lanes, global_env_offset=rank * lanes, device=0, flags=gymrs.AUTO_RESET | gymrs.TRACK_STATS)
+    def make_engine():
+        # chains are opt-in (round 6): an engine that will run them sets its dispatcher up at creation (queue, self-check, hand-over timing), before the loop
+        os.environ["GYMRS_AQL"] = "0" if args.mode == "hip" else str(args.aql)
+        return gymrs.BatchedEngine(0, lanes, global_env_offset=rank * lanes, device=0, flags=args.flags)
+
+    eng = make_engine()
     ring = torch.empty((NBUF, lanes), dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
     for b in range(NBUF):
@@ -96,13 +103,13 @@ def worker(args):
     aql_value = {"hip": "0", "chain": str(args.aql)}
     pre_how = "chain" if args.mode == "chain" else "hip"
 
-    def run(how, k):
+    def run(e, how, k):
         os.environ["GYMRS_AQL"] = aql_value[how]
-        eng.step_many(ptr, stride, NBUF, k)
+        e.step_many(ptr, stride, NBUF, k)
 
     bad, iters, handovers = [], 0, 0
     try:
-        return _loop(args, eng, want, post, pre_how, run, meet, bad, t_twin)
+        return _loop(args, gymrs, eng, make_engine, want, post, pre_how, run, meet, bad, t_twin)
     finally:
         if slots is not None:
             slots[rank] = 1 << 62  # nobody waits for a worker that has left (or died)
@@ -110,42 +117,70 @@ def worker(args):
             shm.close()
 
 
-def _loop(args, eng, want, post, pre_how, run, meet, bad, t_twin):
+def _loop(args, gymrs, eng, make_engine, want, post, pre_how, run, meet, bad, t_twin):
     rank = args.rank
     iters = handovers = 0
+    trips = []  # calls that FAILED LOUDLY (a chain's XCD check, a hand-over that gave up): not wrong results, but the chain's premise did not hold
     meet(1)  # every worker has its engine (queues, self-check, calibration) before anybody loops
     deadline = time.time() + args.seconds
     while time.time() < deadline and len(bad) < 20:
         seed = iters % args.seeds
-        mid, pre, fin = want[seed]
+        mid, pre, fin = want[seed][:3]
         if args.lockstep:
             meet(2 + iters)
-        eng.reset(seed=seed)
-        for i, call in enumerate(PRE_CALLS):
-            run(pre_how, call)
-            if i == 0:
-                eng.sync()
+        try:
+            eng.reset(seed=seed)
+            for i, call in enumerate(PRE_CALLS):
+                run(eng, pre_how, call)
+                if i == 0:
+                    eng.sync()
+                    got = eng.stats()
+                    if not np.array_equal(got, mid):
+                        bad.append({"iter": iters, "seed": seed, "where": "after warm-up", "got": got.tolist(), "want": mid.tolist()})
+            eng.sync()
+            eng.stats_clear()
+            if args.check_clear:
                 got = eng.stats()
-                if not np.array_equal(got, mid):
-                    bad.append({"iter": iters, "seed": seed, "where": "after warm-up", "got": got.tolist(), "want": mid.tolist()})
-        eng.sync()
-        eng.stats_clear()
-        if args.check_clear:
+                if got[1] != 0 or got[2] != 0:
+                    bad.append({"iter": iters, "seed": seed, "where": "right after stats_clear", "got": got.tolist()})
+            for j, (how, k) in enumerate(post):
+                if args.audit and j == 2:  # stream -> chain behind a snapshot LOAD: a call that is thrown away, then the same call again from the restored engine
+                    blob = eng.snapshot()
+                    run(eng, how, k)
+                    eng.restore(blob)
+                run(eng, how, k)
+                if args.audit and j == 1:  # chain -> host copy -> stream write -> chain: the state read out and written back as it is
+                    eng.set_state(eng.get_state())
+                if args.audit and j == 3:  # a step-result read-out right behind a call
+                    eng.get_step_result()
+                if not args.no_sync_between:
+                    eng.sync()
+            if args.audit:  # state bits and the last step's reward / done / truncated against the twin, before the statistics
+                state, result = want[seed][3], want[seed][4]
+                got_state, got_result = eng.get_state(), eng.get_step_result()
+                if not np.array_equal(got_state.view(np.uint32), state.view(np.uint32)):
+                    bad.append({"iter": iters, "seed": seed, "where": "state", "lanes_differing": int(np.count_nonzero((got_state.view(np.uint32) != state.view(np.uint32)).any(axis=0)))})
+                for name, g, w in zip(("reward", "done", "truncated"), got_result, result):
+                    if not np.array_equal(np.asarray(g).view(np.uint8), np.asarray(w).view(np.uint8)):
+                        bad.append({"iter": iters, "seed": seed, "where": name})
             got = eng.stats()
-            if got[1] != 0 or got[2] != 0:
-                bad.append({"iter": iters, "seed": seed, "where": "right after stats_clear", "got": got.tolist()})
-        for how, k in post:
-            run(how, k)
-            if not args.no_sync_between:
+            if not np.array_equal(got, fin):
+                bad.append({"iter": iters, "seed": seed, "where": "end", "got": got.tolist(), "want": fin.tolist(), "pre_clear": pre.tolist(),
+                            "excess_episodes": got[2] - fin[2], "excess_length": got[1] - fin[1]})
+        except gymrs.GymrsError as exc:  # loud: the engine said its arrays may be stale.  A fresh engine goes on (the old one keeps to HIP launches from here)
+            trips.append({"iter": iters, "status": exc.status, "message": str(exc)[:200]})
+            try:
                 eng.sync()
-        got = eng.stats()
-        if not np.array_equal(got, fin):
-            bad.append({"iter": iters, "seed": seed, "where": "end", "got": got.tolist(), "want": fin.tolist(), "pre_clear": pre.tolist(),
-                        "excess_episodes": got[2] - fin[2], "excess_length": got[1] - fin[1]})
+            except gymrs.GymrsError:
+                pass
+            eng.close()
+            eng = make_engine()
+            if len(trips) >= 50:
+                break
         iters += 1
         handovers += sum(1 for how, _ in post if how == "chain") + (len(PRE_CALLS) if pre_how == "chain" else 0)
     extras = json.loads(eng.env_json(0)).get("gymrs", {})
-    print(json.dumps({"rank": rank, "iterations": iters, "chain_calls": handovers, "bad": bad, "twin_s": round(t_twin, 1),
+    print(json.dumps({"rank": rank, "iterations": iters, "chain_calls": handovers, "bad": bad, "trips": trips, "twin_s": round(t_twin, 1),
                       "handover": extras.get("aql_handover"), "dispatcher": extras.get("aql"), "chains": extras.get("aql_chains")}), flush=True)
     eng.close()
     return 0
@@ -176,7 +211,7 @@ def parent(args):
             errs.append(f"rank {r}: killed at the limit")
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]
         if p.returncode != 0 or not lines:
-            errs.append(f"rank {r}: rc {p.returncode}: {err[-400:]}")
+            errs.append(f"rank {r}: rc {p.returncode}: " + " | ".join(ln for ln in err.splitlines() if "resource_tracker" not in ln and "warnings.warn" not in ln)[-600:])
         else:
             recs.append(json.loads(lines[-1]))
     shm.close()
@@ -185,10 +220,11 @@ def parent(args):
     except FileNotFoundError:  # (a worker's resource tracker may have removed the name already)
         pass
     bad = [dict(b, rank=r["rank"]) for r in recs for b in r["bad"]]
+    trips = [dict(t, rank=r["rank"]) for r in recs for t in r.get("trips", [])]
     summary = {"tool": "handover_amp", "mode": args.mode, "handover": args.handover, "aql": args.aql, "fences": args.fences or None, "lockstep": args.lockstep,
-               "check_clear": args.check_clear, "procs": args.procs, "lanes": args.lanes, "seconds": args.seconds, "wall_s": round(time.time() - t0, 1),
+               "check_clear": args.check_clear, "audit": args.audit, "flags": args.flags, "procs": args.procs, "lanes": args.lanes, "seconds": args.seconds, "wall_s": round(time.time() - t0, 1),
                "iterations": sum(r["iterations"] for r in recs), "chain_calls": sum(r["chain_calls"] for r in recs),
-               "wrong_iterations": len(bad), "bad": bad[:12], "handovers_seen": sorted({str(r["handover"]) for r in recs}), "errors": errs}
+               "wrong_iterations": len(bad), "bad": bad[:12], "loud_failures": len(trips), "trips": trips[:6], "handovers_seen": sorted({str(r["handover"]) for r in recs}), "dispatchers": sorted({str(r["dispatcher"]) for r in recs}), "errors": errs}
     print(json.dumps(summary), flush=True)
     return 1 if (bad or errs) else 0
 
@@ -206,6 +242,9 @@ def main():
     ap.add_argument("--seeds", type=int, default=4)
     ap.add_argument("--lockstep", action="store_true")
     ap.add_argument("--check-clear", action="store_true")
+    ap.add_argument("--audit", action="store_true", help="every hand-over class per iteration (VERDICT r5 next #2): state read-out + write-back, snapshot + restore, step-result "
+                                                         "read-out between the calls; state bits and step results compared with the twin as well")
+    ap.add_argument("--flags", type=int, default=3, help="engine flags: 3 = AUTO_RESET | TRACK_STATS (the bench), 7 = + TIME_LIMIT (refresh kernels and the truncated memset between launches)")
     ap.add_argument("--no-sync-between", action="store_true", help="no gymrs_sync between the calls after the clear")
     ap.add_argument("--worker", action="store_true")
     ap.add_argument("--rank", type=int, default=0)
