@@ -185,9 +185,10 @@ impl Engine {
     }
 
     /// `n_steps` consecutive `Env::step`s, step `t` taking its actions from buffer `t % n_buffers` of a ring of device buffers
-    /// `stride_bytes` apart: ONE call, asynchronous on the engine's stream.  Calls of 8 steps and more are submitted as a chain
-    /// through the engine's own HSA queue (release fence only at the end of the chain: 4.9 instead of 6.4 us per 2^20-lane
-    /// CartPole step); a caller that has K action buffers ready should prefer this to K `step_device` calls.
+    /// `stride_bytes` apart: ONE call, asynchronous on the engine's stream.  HIP launches by default (since round 6); with `GYMRS_AQL=1` in the
+    /// process environment calls of 8 steps and more are submitted as a chain through the engine's own HSA queue (release fence only at the
+    /// end of the chain: 4.9 instead of 6.4 us per 2^20-lane CartPole step; one process per GPU -- INTEGRATION.md "gymrs_step_many").  A caller
+    /// that has K action buffers ready should prefer this to K `step_device` calls either way (one FFI call, one host loop).
     ///
     /// # Safety
     /// `actions_dev` must be a device address of `n_buffers` buffers of at least `len()` bytes each, valid until `sync()`.
