@@ -11,6 +11,8 @@ export TMPDIR=/tmp
 REPO=$PWD
 SHA=$(python -c "import bench; print(bench.kernel_source_sha16())")
 echo "kernel_source_sha16 $SHA" > "$OUT/${TAG}_sha.txt"
+# the counter tool of step 1 is git-ignored like every built file: a rebuilt container does not have it (round 6 lost a pass to that)
+[ -f tools/devcount/libgymrs_devcount.so ] || g++ -O2 -std=c++17 -fPIC -shared -D__HIP_PLATFORM_AMD__ tools/devcount/gymrs_devcount.cpp -I/opt/rocm/include -L/opt/rocm/lib -lrocprofiler-sdk -o tools/devcount/libgymrs_devcount.so
 
 # 0. the GPU suite and smoke(), as the driver runs them
 timeout 1800 python -m pytest tests -m gpu -x -q > "$OUT/${TAG}_pytest_gpu_full.log" 2>&1; grep -E "passed|failed" "$OUT/${TAG}_pytest_gpu_full.log" | tail -2 > "$OUT/${TAG}_pytest_gpu.log"
