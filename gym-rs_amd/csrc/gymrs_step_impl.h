@@ -198,42 +198,103 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 // THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
+// Where the kernel arguments come from (round 6; Env::kLoadsAheadOfArguments: CartPole).  The six leading scalars arrive PRELOADED in SGPRs; everything else
+// (StepArgs, Consts) lies in the kernel-argument segment behind a scalar-load round trip -- two of them, in fact, and 16 v_writelane of spilled SGPRs, because the
+// compiler fetches every used by-value argument at the top of the kernel and holds all of it live: a wave issued its first state load only after both
+// (profiles/r06_wave_phase_trace_2p21.log: "issue loads" 650-1170 cycles per wave).  For such an env the body never names `rest` / `c`: it issues the tile's loads
+// from the preloaded scalars alone and THEN reads the segment through its pointer (same bytes, same layout: StepKernArgs), so that the argument fetch runs in the
+// shadow of the state loads.  profiles/r06_loads_before_arguments.log: CartPole 2^20 lanes 6.39-6.47 -> 6.14-6.26 us in five box / run pairs out of five, other
+// sizes within +-1.5 %; MountainCar and Pendulum gain at 2^20 lanes too but lose 3-6 % from 2^22 on (in EITHER order of this structure): they keep the by-value form.
+template <class Env>
+struct KernArgView {
+    using Consts = typename Env::Consts;
+    static __device__ __forceinline__ void fetch(StepArgs& a, Consts& c)
+    {
+        // (the segment lies in the constant address space; the cast to a plain pointer is folded back by address-space inference: scalar loads, and the pointer
+        // members stay what kernel-argument pointers are -- global.  Copied word by word instead, they would come out as flat pointers: 50 flat_* instructions.)
+        const char* kp = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+        __builtin_memcpy(&a, kp + offsetof(StepKernArgs<Consts>, rest), sizeof(StepArgs));
+        __builtin_memcpy(&c, kp + offsetof(StepKernArgs<Consts>, c), sizeof(Consts));
+    }
+};
+
 template <class Env, int VEC, uint32_t FLAGS, int THREADS>
 __device__ __forceinline__ void step_kernel_body(float* s0, float* s1, float* s2, float* s3, const void* action, uint64_t n_fast, const StepArgs& rest,
-                                                 const typename Env::Consts& c)
+                                                 const typename Env::Consts& c_by_value)
 {
     constexpr int LPB = THREADS * VEC;
     __shared__ ResetLds<Env, VEC, THREADS> lds;
-    StepArgs a = rest;
-    a.s[0] = s0;
-    a.s[1] = s1;
-    a.s[2] = s2;
-    a.s[3] = s3;
-    a.action = action;
     // wave-uniform: every wavefront whose 64 * VEC lanes all exist runs the unguarded body; only the one that
     // straddles n (and the empty ones behind it) takes the guarded per-lane code.  n_fast (a preloaded scalar
     // argument) is n -- or 0 when the caller's action buffer is not aligned for the vector load, which sends
     // every wavefront through the guarded code (per-lane action loads); the real n travels in StepArgs.
-    if constexpr (kStepTiles == 1) {
-        if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
-            step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x);
-        else
-            step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x);
-    } else {
-        // (developer builds, GYMRS_EXP_TILES) a workgroup steps kStepTiles consecutive tiles, the loads of tile j + 1 issued before the
-        // arithmetic of tile j: more bytes in flight per resident wave where a launch is several generations of waves
-        const uint32_t vb0 = blockIdx.x * (uint32_t)kStepTiles;
-        if ((uint64_t)(vb0 + kStepTiles - 1) * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast) {
-            TileRegs<Env, VEC, FLAGS> d[2];
-            load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)vb0 * LPB + (uint64_t)threadIdx.x * VEC, d[0]);
+    if constexpr (kStepTiles == 1 && Env::kLoadsAheadOfArguments) {
+        StepArgs a;
+        typename Env::Consts c;
+        if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast) {
+#ifdef GYMRS_TRACE_TIMES
+            const unsigned long long t_start = __builtin_amdgcn_s_memtime(); // (stamp 0 is stored below: the trace buffer's pointer is an argument too)
+#endif
+            using R = TileRegs<Env, VEC, FLAGS>;
+            using Action = typename Env::Action;
+            const uint64_t base = (uint64_t)blockIdx.x * LPB + (uint64_t)threadIdx.x * VEC;
+            float* const sp[4] = {s0, s1, s2, s3};
+            TileRegs<Env, VEC, FLAGS> d;
 #pragma unroll
-            for (int j = 0; j < kStepTiles; ++j) {
-                if (j + 1 < kStepTiles) load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)(vb0 + j + 1) * LPB + (uint64_t)threadIdx.x * VEC, d[(j + 1) & 1]);
-                step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, vb0 + j, d[j & 1]);
-            }
+            for (int j = 0; j < Env::kState; ++j) d.st[j] = load_vec<float, VEC, R::NT_SL>(sp[j], base, n_fast, true, 0.0f);
+            d.act = load_vec<Action, VEC, R::NT_A>(static_cast<const Action*>(action), base, n_fast, true, Action(0));
+            __builtin_amdgcn_sched_barrier(0); // nothing of the argument fetch below moves ahead of these loads
+            KernArgView<Env>::fetch(a, c);
+            a.s[0] = s0;
+            a.s[1] = s1;
+            a.s[2] = s2;
+            a.s[3] = s3;
+            a.action = action;
+#ifdef GYMRS_TRACE_TIMES
+            if (a.trace && (threadIdx.x & 63u) == 0) a.trace[((size_t)blockIdx.x * a.trace_wpb + (threadIdx.x >> 6)) * 8 + 0] = t_start;
+#endif
+            // (the arrays only some flag sets read: their pointers travel in StepArgs)
+            if (Env::kHasBeyond && !R::AUTO) d.beyond = load_vec<uint8_t, VEC, R::NT_SL>(a.beyond, base, a.n, true, uint8_t(0));
+            if (R::TLIM && !Env::kNeverTerminates) d.ep_start = load_vec<uint32_t, VEC, false>(a.ep_start, base, a.n, true, 0u);
+            step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x, d);
         } else {
-            for (int j = 0; j < kStepTiles; ++j)
-                if ((uint64_t)(vb0 + j) * LPB < rest.n) step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, vb0 + j);
+            KernArgView<Env>::fetch(a, c);
+            a.s[0] = s0;
+            a.s[1] = s1;
+            a.s[2] = s2;
+            a.s[3] = s3;
+            a.action = action;
+            step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x);
+        }
+    } else {
+        const typename Env::Consts& c = c_by_value;
+        StepArgs a = rest;
+        a.s[0] = s0;
+        a.s[1] = s1;
+        a.s[2] = s2;
+        a.s[3] = s3;
+        a.action = action;
+        if constexpr (kStepTiles == 1) {
+            if ((uint64_t)blockIdx.x * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast)
+                step_block<Env, VEC, FLAGS, THREADS, true>(a, c, lds, blockIdx.x);
+            else
+                step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, blockIdx.x);
+        } else {
+            // (developer builds, GYMRS_EXP_TILES) a workgroup steps kStepTiles consecutive tiles, the loads of tile j + 1 issued before the
+            // arithmetic of tile j: more bytes in flight per resident wave where a launch is several generations of waves
+            const uint32_t vb0 = blockIdx.x * (uint32_t)kStepTiles;
+            if ((uint64_t)(vb0 + kStepTiles - 1) * LPB + (uint64_t)((threadIdx.x >> 6) + 1) * (64 * VEC) <= n_fast) {
+                TileRegs<Env, VEC, FLAGS> d[2];
+                load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)vb0 * LPB + (uint64_t)threadIdx.x * VEC, d[0]);
+#pragma unroll
+                for (int j = 0; j < kStepTiles; ++j) {
+                    if (j + 1 < kStepTiles) load_tile<Env, VEC, FLAGS, true>(a, (uint64_t)(vb0 + j + 1) * LPB + (uint64_t)threadIdx.x * VEC, d[(j + 1) & 1]);
+                    step_block_loaded<Env, VEC, FLAGS, THREADS, true>(a, c, lds, vb0 + j, d[j & 1]);
+                }
+            } else {
+                for (int j = 0; j < kStepTiles; ++j)
+                    if ((uint64_t)(vb0 + j) * LPB < rest.n) step_block<Env, VEC, FLAGS, THREADS, false>(a, c, lds, vb0 + j);
+            }
         }
     }
 }

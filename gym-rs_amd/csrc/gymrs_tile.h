@@ -129,6 +129,7 @@ struct CartPoleT {
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
     static constexpr int kThreads = 512; // work-items per workgroup of the per-step kernel at >= 2^20 lanes: 8 waves measured 2 % faster than 4
+    static constexpr bool kLoadsAheadOfArguments = true; // step_kernel_body (round 6): 2^20 lanes 6.39-6.47 -> 6.14-6.26 us, five box / run pairs out of five
     __device__ static bool valid(Action a) { return a < 2; } // Discrete(2).contains, discrete.rs:14-19
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -165,6 +166,7 @@ struct MountainCarT {
     static constexpr bool kHasObsExtra = false;
     static constexpr bool kNeverTerminates = false;
     static constexpr int kThreads = 256; // (512 measured 1-2 % slower for this short kernel)
+    static constexpr bool kLoadsAheadOfArguments = false; // (round 6: -4 % / level at 2^20 lanes, but +3 .. +4 % from 2^22 on, in either order of the new structure)
     __device__ static bool valid(Action a) { return a < 3; } // Discrete(3)
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
@@ -200,6 +202,7 @@ struct PendulumT { // spec-derived, not in the reference
     // kernel argument (StepArgs::truncate_all) instead of a per-lane compare against a dense ep_start read.
     static constexpr bool kNeverTerminates = true;
     static constexpr int kThreads = 256;
+    static constexpr bool kLoadsAheadOfArguments = false; // (round 6: -9 % at 2^20 lanes on two boxes, but -2 % / +6 % at its BASELINE size 2^22: not taken)
     __device__ static bool valid(Action) { return true; } // a Box action is clipped, never rejected
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
