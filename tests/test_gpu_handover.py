@@ -7,7 +7,7 @@ Two runs: the DEFAULT submission (HIP launches on the engine's stream) and the o
 a hand-over pair stream -> chain -> stream).  A WRONG count is a failure on either.  A chain call that fails LOUDLY (the per-launch XCD check, GYMRS_EHIP) is
 not: the pytest process holds a HIP context of its own, so this run has nine GPU processes, more than the GPU's eight hardware process slots -- the kernel
 driver then time-slices whole processes, remaps their queues, and a chain's workgroups can start on another XCD in mid-chain; the check exists to say so
-(profiles/r06_handover_amp_12_processes_*.log: ~1 loud failure per 10^5 chain calls with 12 processes, none with 8; never a wrong count).  Round 6's soak of
+(profiles/r06_handover_amp_12_processes_*.log: ~1 loud failure per 10^5 chain calls with 12 processes, one in 2.3 M with 8; never a wrong count).  Round 6's soak of
 this tool: > 10^6 chain calls without a wrong count (profiles/r06_handover_amp_*.log)."""
 import json
 import spawn_server
