@@ -23,7 +23,7 @@ def main():
     (P / "r06_size_sweep.log").write_text(
         "# profiles/r06_size_sweep.log -- step vs IN-PLACE copy of its own footprint over sizes, both call shapes, all three envs (tools/size_sweep.py, the round's evidence run\n"
         "# tools/refresh_evidence.sh r06, one box; the copy is tools/copy_probe's -- a tool of its own since round 5 -- submitted the way the steps are: launches of a chain /\n"
-        "# HIP launches; no hint, loads + stores hinted, stores hinted; 8 action buffers; hashed non-zero words).  Kernels unchanged since round 4: compare profiles/r05_size_sweep.log.\n"
+        "# HIP launches; no hint, loads + stores hinted, stores hinted; 8 action buffers; hashed non-zero words).  CartPole's kernel issues its loads ahead of its argument fetch since round 6 (profiles/r06_loads_before_arguments.log), the others are round 4's: compare profiles/r05_size_sweep.log.\n"
         + "\n".join(parts) + "\n")
     t = clean((G / "r06_submission_by_size.log").read_text())
     import re
