@@ -198,13 +198,14 @@ __device__ __forceinline__ void step_block(const StepArgs& a, const typename Env
 // deliver them in SGPRs at wave launch instead of behind an s_load round trip; the rest travels in StepArgs.
 // THREADS work-items per workgroup: 256, or Env::kThreads (CartPole: 512) for launches big enough to still put two
 // workgroups on every CU -- small batches want many small workgroups (16384 lanes: 3.0 vs 3.6 us).
-// Where the kernel arguments come from (round 6; Env::kLoadsAheadOfArguments: CartPole).  The six leading scalars arrive PRELOADED in SGPRs; everything else
+// Where the kernel arguments come from (round 6; Env::kLoadsAheadOfArguments: CartPole, Pendulum).  The six leading scalars arrive PRELOADED in SGPRs; everything else
 // (StepArgs, Consts) lies in the kernel-argument segment behind a scalar-load round trip -- two of them, in fact, and 16 v_writelane of spilled SGPRs, because the
 // compiler fetches every used by-value argument at the top of the kernel and holds all of it live: a wave issued its first state load only after both
 // (profiles/r06_wave_phase_trace_2p21.log: "issue loads" 650-1170 cycles per wave).  For such an env the body never names `rest` / `c`: it issues the tile's loads
 // from the preloaded scalars alone and THEN reads the segment through its pointer (same bytes, same layout: StepKernArgs), so that the argument fetch runs in the
-// shadow of the state loads.  profiles/r06_loads_before_arguments.log: CartPole 2^20 lanes 6.39-6.47 -> 6.14-6.26 us in five box / run pairs out of five, other
-// sizes within +-1.5 %; MountainCar and Pendulum gain at 2^20 lanes too but lose 3-6 % from 2^22 on (in EITHER order of this structure): they keep the by-value form.
+// shadow of the state loads.  profiles/r06_loads_before_arguments.log: CartPole 2^20 lanes 6.39-6.47 -> 6.09-6.31 us in eight run pairs of eight on four boxes,
+// other sizes within +-1.5 %; Pendulum (one early wait, no spill) 2^20 lanes 5.9 -> 5.4 us, 2^22 -2 .. -5 % on three boxes and +6 % once.  MountainCar's kernel
+// already had its loads ahead of the wait and loses 1-4 % from 2^22 lanes on in this structure (EITHER order): it keeps the by-value form, byte-identical to round 5's.
 template <class Env>
 struct KernArgView {
     using Consts = typename Env::Consts;

@@ -202,7 +202,7 @@ struct PendulumT { // spec-derived, not in the reference
     // kernel argument (StepArgs::truncate_all) instead of a per-lane compare against a dense ep_start read.
     static constexpr bool kNeverTerminates = true;
     static constexpr int kThreads = 256;
-    static constexpr bool kLoadsAheadOfArguments = false; // (round 6: -9 % at 2^20 lanes on two boxes, but -2 % / +6 % at its BASELINE size 2^22: not taken)
+    static constexpr bool kLoadsAheadOfArguments = true; // step_kernel_body (round 6): 2^20 lanes -9 % on four boxes; its BASELINE size 2^22: -2 .. -5 % on three boxes (both ring sizes), +6 % once
     __device__ static bool valid(Action) { return true; } // a Box action is clipped, never rejected
     __device__ static void advance(const Consts& c, float* st, Action a, float& reward, bool& done)
     {
